@@ -1,0 +1,159 @@
+"""bench.py -- integrated latent frames/s of the Neural-ODE hot path on MI355X.
+
+One "step" = one `DiffEqSolver.forward(z0, t)` over one batch of synthetic Moving-MNIST-shaped latents
+(BASELINE.json configs[1]: ODEConvGRU latents (B,64,16,16), 10 output frames = 9 rk4(3/8) intervals, fp32).
+Inputs are resident in HBM before the timed region.  With --gpus N every rank integrates its own batch
+(weak scaling, no data-path collective: samples are independent under a fixed-grid solver).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- dominant kernel (conv_q4_kernel<3,2,5>, exact-fp32 MFMA): algorithmic FLOP per launch /
+                  average launch duration measured with HIP events over the timed region;
+  cpu_baseline -- the oracle (CPU restatement of torchdiffeq 0.2.1 on torch-CPU convs) timed on this
+                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]: 64)")
+    p.add_argument("--frames", type=int, default=10, help="output time points (10 -> 9 intervals)")
+    p.add_argument("--method", default="rk4")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    return p.parse_args()
+
+
+def conv_flops(f_channels, batch):
+    return sum(2 * batch * ci * co * 9 * 256 for ci, co in zip(f_channels[:-1], f_channels[1:]))
+
+
+def cpu_baseline(state, z0, t, method, budget_s):
+    """Time the oracle on the host cores: whole trajectories of the same workload until ~budget_s."""
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    ws, bs = rm.split_convnet_state(state, "gradient_net.")
+    f = rm.ode_func(ws, bs)
+    frames = z0.shape[0] * len(t)
+    with torch.no_grad():
+        torchdiffeq_ref.odeint(f, z0, t, method=method)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            torchdiffeq_ref.odeint(f, z0, t, method=method)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= 50:
+                break
+    return {"value": frames * n / el, "unit": "latent frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full trajectories of the same workload (B={z0.shape[0]}, T={len(t)}, {method}), "
+                      f"{el:.1f} s of torch-CPU fp32, no_grad"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import ode_rl_amd
+    torch.manual_seed(0)
+    f = ode_rl_amd.ODEFunc(n_inputs=64, n_outputs=64, n_layers=3, n_units=64, downsize=False, nonlinear="relu",
+                           final_act=False)
+    state = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    f = f.to(dev)
+    solver = ode_rl_amd.DiffEqSolver(f, a.method, device=dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    z0_cpu = torch.randn(a.batch, 64, 16, 16, generator=g) * 0.5
+    z0 = z0_cpu.to(dev)
+    T = a.frames
+    t_cpu = torch.arange(T, 2 * T, dtype=torch.float64) / (2 * T)
+    t = t_cpu.to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = solver(z0, t)
+        sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(a.steps):
+            out = solver(z0, t)
+        ev1.record()
+        sync()
+        wall = time.perf_counter() - t0
+    assert out.shape == (T, a.batch, 64, 16, 16) and bool(torch.isfinite(out).all())
+    dev_ms = ev0.elapsed_time(ev1)
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+
+    if rank == 0:
+        nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
+        n_convs = 5
+        launches = nfe_per_step * n_convs * a.steps
+        flop_per_launch = conv_flops([64, 64], a.batch)             # one 64->64 3x3 layer over the batch
+        per_launch_s = dev_ms * 1e-3 / launches                      # HIP events, incl. inter-kernel gaps
+        achieved = flop_per_launch / per_launch_s / 1e12
+        res = {
+            "metric": "integrated latent frames/sec (ODEConvGRU, MovingMNIST)",
+            "value": world * a.batch * T * a.steps / wall,
+            "unit": "latent frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
+                                   f"({T - 1} intervals), fixed-step {a.method} (3/8 rule), f = 5x conv3x3(64->64)+ReLU, "
+                                   "forward only (BASELINE configs[1])",
+                       "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv_q4_kernel<3,2,5>", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None,
+                         "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
+                         "launches_timed": launches},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(state, z0_cpu, t_cpu, a.method, a.cpu_seconds)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+/* odecgru_hip.h -- C ABI of the MI355X (gfx950) Neural-ODE hot path.
+ *
+ * The reference (jithendaraa/ODE-RL) has no FFI: its hot path is Python calling
+ * `torchdiffeq.odeint(func, y0, t, rtol=, atol=, method=)` (modules/DiffEqSolver.py:37,45-46)
+ * on a conv dynamics `f` built by `utils.create_convnet` (helpers/utils.py:158-183), plus the
+ * Euler+ConvGRU encoder loop (modules/ODEConvGRUCell.py:39-78, modules/ConvGRUCell.py:55-86).
+ * These entry points are what a native binding for that path would bind:
+ * plain pointers and sizes, device pointers are HIP device memory, `stream` is a hipStream_t.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ODEHIP_E* code on failure;
+ *     odehip_last_error() returns a static string for the calling thread.
+ *   - enqueue-only: nothing synchronises the stream, nothing allocates device memory;
+ *     scratch comes from caller-provided workspaces sized by the *_bytes() queries.
+ *   - boundary tensors are fp32 NCHW, contiguous, H = W = 16 (the reference's latent map,
+ *     models/ODEConvGRU.py:18-20 with resolution 64, n_downs 2).  Internally activations use
+ *     the "Q4" layout [B][C/4][256 pixels][4 channels].
+ */
+#ifndef ODECGRU_HIP_H
+#define ODECGRU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODEHIP_MAX_LAYERS 8
+#define ODEHIP_MAX_STAGES 7
+
+enum {
+  ODEHIP_OK = 0,
+  ODEHIP_EINVAL = -1,   /* bad shape / argument (the Python side raises ValueError) */
+  ODEHIP_EHIP = -2,     /* a HIP runtime call failed */
+  ODEHIP_ENOTCONV = -3, /* adaptive solver hit max_num_steps / dt underflow (AssertionError in torchdiffeq) */
+  ODEHIP_ENAN = -4      /* non-finite state (the reference asserts: modules/ODEConvGRUCell.py:56,59) */
+};
+
+/* fixed-grid methods of torchdiffeq (_impl/fixed_grid.py); rk4 is the 3/8 rule */
+enum { ODEHIP_EULER = 0, ODEHIP_MIDPOINT = 1, ODEHIP_RK4 = 2, ODEHIP_DOPRI5 = 3 };
+
+const char* odehip_last_error(void);
+int odehip_version(void);
+
+/* ---- layout + weight packing -------------------------------------------------------------- */
+
+/* number of floats of the MFMA-ordered image of a (cout, cin, ks, ks) conv weight */
+size_t odehip_packed_weight_floats(int cout, int cin, int ks);
+
+/* OIHW fp32 -> packed image.  transpose_flip != 0 packs the weights of the input-gradient
+ * convolution (dgrad): W'[ci][co][ks-1-dy][ks-1-dx], i.e. a conv with cin/cout swapped.
+ * Replaces: the implicit cuDNN/MIOpen weight handling behind nn.Conv2d (helpers/utils.py:167-177). */
+int odehip_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
+                            int transpose_flip, void* stream);
+
+int odehip_nchw_to_q4(const float* src_nchw, float* dst_q4, int batch, int channels, void* stream);
+int odehip_q4_to_nchw(const float* src_q4, float* dst_nchw, int batch, int channels, void* stream);
+
+/* ---- one convolution layer on 16x16 maps (building block; exposed for tests) ---------------- */
+
+typedef struct odehip_conv_desc {
+  const float* src1;      /* Q4 input, channels [0, cin1)                                     */
+  const float* src2;      /* Q4 input, channels [cin1, cin); NULL when cin1 == cin (torch.cat) */
+  int cin1, cin, cout, ks, batch;
+  const float* w_packed;  /* from odehip_pack_conv_weight                                      */
+  const float* bias;      /* cout floats or NULL                                               */
+  const float* zero_page; /* >= 1 KiB of zeros in device memory (row halo source)              */
+  float* dst;             /* Q4 output                                                        */
+  int relu;               /* fuse ReLU into the epilogue                                      */
+} odehip_conv_desc;
+
+int odehip_conv_q4(const odehip_conv_desc* d, void* stream);
+
+/* ---- the dynamics f(t, y) = gradient_net(y)  (modules/DiffEqSolver.py:71-80) ---------------- */
+
+typedef struct odehip_convstack {
+  int n_convs;                           /* create_convnet: n_layers + 2 (helpers/utils.py:166-177) */
+  int ks;                                /* 3                                                       */
+  int channels[ODEHIP_MAX_LAYERS + 1];   /* channels[i] -> channels[i+1]                            */
+  const float* w_packed[ODEHIP_MAX_LAYERS];
+  const float* bias[ODEHIP_MAX_LAYERS];
+  int final_tanh;                        /* final_act=True appends Tanh (helpers/utils.py:179-181)  */
+} odehip_convstack;
+
+size_t odehip_convstack_workspace_bytes(const odehip_convstack* f, int batch);
+
+/* y, out: NCHW fp32 (batch, channels[0]|channels[n], 16, 16).  negate != 0 returns -f (backwards=True). */
+int odehip_convstack_forward(const odehip_convstack* f, const float* y_nchw, float* out_nchw, int batch,
+                             int negate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- odeint, fixed grid: euler / midpoint / rk4(3/8)  (torchdiffeq FixedGridODESolver) ------ */
+
+size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int method,
+                                     int save_for_backward);
+
+/* z0: (B,C,16,16) NCHW; t_host: n_times float64 on the HOST, strictly increasing;
+ * out: (n_times,B,C,16,16) NCHW, out[0] = z0.  One step per output interval. */
+int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
+                        int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODECGRU_HIP_H */

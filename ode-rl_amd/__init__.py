@@ -1,0 +1,10 @@
+"""MI355X-native Neural-ODE hot path of jithendaraa/ODE-RL.
+
+Public surface = the reference's: `odeint`, `DiffEqSolver`, `ODEFunc`, `create_convnet`.
+"""
+from . import _lib  # noqa: F401
+from .odeint import odeint  # noqa: F401
+from .helpers.utils import create_convnet  # noqa: F401
+from .modules.DiffEqSolver import DiffEqSolver, ODEFunc  # noqa: F401
+
+__all__ = ["odeint", "DiffEqSolver", "ODEFunc", "create_convnet"]

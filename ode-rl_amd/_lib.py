@@ -1,0 +1,97 @@
+"""ctypes binding of libodecgru_hip.so (the C ABI declared in include/odecgru_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute call goes through
+the C ABI with raw pointers.  There is NO fallback: if the library is missing the import of any
+compute entry point raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libodecgru_hip.so")
+
+MAX_LAYERS = 8
+MAX_STAGES = 7
+EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
+METHODS = {"euler": EULER, "midpoint": MIDPOINT, "rk4": RK4, "dopri5": DOPRI5}
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("src1", ctypes.c_void_p), ("src2", ctypes.c_void_p),
+        ("cin1", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ks", ctypes.c_int),
+        ("batch", ctypes.c_int),
+        ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("zero_page", ctypes.c_void_p),
+        ("dst", ctypes.c_void_p), ("relu", ctypes.c_int),
+    ]
+
+
+class ConvStack(ctypes.Structure):
+    _fields_ = [
+        ("n_convs", ctypes.c_int), ("ks", ctypes.c_int),
+        ("channels", ctypes.c_int * (MAX_LAYERS + 1)),
+        ("w_packed", ctypes.c_void_p * MAX_LAYERS),
+        ("bias", ctypes.c_void_p * MAX_LAYERS),
+        ("final_tanh", ctypes.c_int),
+    ]
+
+
+class OdeHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); the parity of this table with include/odecgru_hip.h is tested on CPU
+SIGNATURES = {
+    "odehip_last_error": (ctypes.c_char_p, []),
+    "odehip_version": (ctypes.c_int, []),
+    "odehip_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "odehip_pack_conv_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_nchw_to_q4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_q4_to_nchw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_conv_q4": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "odehip_convstack_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int]),
+    "odehip_convstack_forward": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_void_p]),
+    "odehip_odeint_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int]),
+    "odehip_odeint_fixed": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p]),
+}
+
+
+def load():
+    """Load the shared library once; raise if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OdeHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ode-rl_amd/csrc`.  The HIP path has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    """Map the C status code to the exception the reference's Python path would raise."""
+    if rc == 0:
+        return
+    msg = load().odehip_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    if rc in (-3, -4):
+        raise AssertionError(msg)
+    raise OdeHipError(f"odehip status {rc}: {msg}")

@@ -1,0 +1,100 @@
+// layout.hip -- boundary layout conversion and weight packing (HBM-bound helpers, gfx950).
+//
+//   NCHW (the reference's tensors, modules/DiffEqSolver.py:24-52)  <->  Q4 [b][c/4][pixel][4]
+//   OIHW conv weight (nn.Conv2d, helpers/utils.py:167-177)          ->  MFMA-ordered LDS image
+#include "odehip_internal.h"
+
+namespace odehip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one thread = one (b, quad, pixel): reads 4 channel planes (coalesced over pixels), writes 16 B.
+__global__ __launch_bounds__(256) void nchw_to_q4_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int total /* b*quads*256 */, int quads) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = idx & 255;
+  const int bq = idx >> 8;  // b*quads + q
+  const float* s = src + (size_t)bq * 4 * kPix + p;
+  f32x4 v = {s[0], s[kPix], s[2 * kPix], s[3 * kPix]};
+  *(f32x4*)(dst + (size_t)idx * 4) = v;
+  (void)quads;
+}
+
+__global__ __launch_bounds__(256) void q4_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = idx & 255;
+  const int bq = idx >> 8;
+  const f32x4 v = *(const f32x4*)(src + (size_t)idx * 4);
+  float* d = dst + (size_t)bq * 4 * kPix + p;
+  d[0] = v.x; d[kPix] = v.y; d[2 * kPix] = v.z; d[3 * kPix] = v.w;
+}
+
+// packed[ct][m][tap][kq][i][s] = W[co = ct*32+i][ci = 8m+4kq+s][tap]      (transpose_flip == 0)
+//                              = W[co' = ci][ci' = co][taps-1-tap]        (dgrad weights)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                          int cout, int cin, int taps, int transpose_flip,
+                                                          int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int r = idx;
+  const int s = r & 3; r >>= 2;
+  const int i = r & 31; r >>= 5;
+  const int kq = r & 1; r >>= 1;
+  const int tap = r % taps; r /= taps;
+  const int mcount = cin / 8;
+  const int m = r % mcount;
+  const int ct = r / mcount;
+  const int co = ct * 32 + i, ci = 8 * m + 4 * kq + s;
+  float v;
+  if (!transpose_flip) {
+    v = w[((size_t)co * cin + ci) * taps + tap];
+  } else {
+    // source tensor is (cin_of_this_conv = original cout ... ) : original layout W[o][i'][tap] with
+    // o = ci (this conv's input channel), i' = co (this conv's output channel)
+    v = w[((size_t)ci * cout + co) * taps + (taps - 1 - tap)];
+  }
+  out[idx] = v;
+}
+
+}  // namespace odehip
+
+using namespace odehip;
+
+extern "C" size_t odehip_packed_weight_floats(int cout, int cin, int ks) {
+  return (size_t)cout * cin * ks * ks;
+}
+
+extern "C" int odehip_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
+                                       int transpose_flip, void* stream) {
+  ODEHIP_REQUIRE(w_oihw && w_packed, "pack_conv_weight: null pointer");
+  ODEHIP_REQUIRE(cout > 0 && cout % 32 == 0, "pack_conv_weight: cout must be a multiple of 32 (got %d)", cout);
+  ODEHIP_REQUIRE(cin > 0 && cin % 8 == 0, "pack_conv_weight: cin must be a multiple of 8 (got %d)", cin);
+  ODEHIP_REQUIRE(ks == 1 || ks == 3 || ks == 5, "pack_conv_weight: kernel size %d unsupported", ks);
+  const int total = cout * cin * ks * ks;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     w_packed, cout, cin, ks * ks, transpose_flip, total);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_nchw_to_q4(const float* src, float* dst, int batch, int channels, void* stream) {
+  ODEHIP_REQUIRE(src && dst, "nchw_to_q4: null pointer");
+  ODEHIP_REQUIRE(batch > 0 && channels > 0 && channels % 4 == 0, "nchw_to_q4: bad shape (%d, %d)", batch, channels);
+  const int total = batch * (channels / 4) * kPix;
+  hipLaunchKernelGGL(nchw_to_q4_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, total,
+                     channels / 4);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_q4_to_nchw(const float* src, float* dst, int batch, int channels, void* stream) {
+  ODEHIP_REQUIRE(src && dst, "q4_to_nchw: null pointer");
+  ODEHIP_REQUIRE(batch > 0 && channels > 0 && channels % 4 == 0, "q4_to_nchw: bad shape (%d, %d)", batch, channels);
+  const int total = batch * (channels / 4) * kPix;
+  hipLaunchKernelGGL(q4_to_nchw_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, total);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}

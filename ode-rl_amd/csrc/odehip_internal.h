@@ -1,0 +1,70 @@
+// Internal declarations shared by the HIP translation units of libodecgru_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/odecgru_hip.h"
+
+namespace odehip {
+
+constexpr int kHW = 16;           // latent maps are 16x16 (models/ODEConvGRU.py:18-20)
+constexpr int kPix = kHW * kHW;   // 256 pixels
+constexpr int kQuadBytes = kPix * 16;  // one channel-quad plane of the Q4 layout: 256 px * 4 ch * 4 B
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define ODEHIP_CHECK_HIP(expr)                                   \
+  do {                                                           \
+    hipError_t e__ = (expr);                                     \
+    if (e__ != hipSuccess) return ::odehip::hip_fail(e__, #expr); \
+  } while (0)
+
+#define ODEHIP_REQUIRE(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::odehip::set_error(__VA_ARGS__);      \
+      return ODEHIP_EINVAL;                  \
+    }                                        \
+  } while (0)
+
+// ---- stage-combine epilogue of the LAST conv of f (Runge-Kutta bookkeeping fused in) -------
+// k_cur = conv output.  Optional outputs, all Q4 unless stated:
+//   k_out             <- k_cur
+//   out1              <- y + h * ( sum_{j<n_prev} c1[j]*k_prev[j] + c1[n_prev]*k_cur )
+//   out2 (+out2_nchw) <- y + h * ( sum c2 ... )            (used for the step result y_{n+1})
+// h = *h_ptr (device scalar; the step size of this interval), so one captured graph serves any t.
+struct CombineArgs {
+  const float* y;
+  const float* k_prev[ODEHIP_MAX_STAGES];
+  float* k_out;
+  float* out1;
+  float* out2;
+  float* out2_nchw;
+  const float* h_ptr;
+  int n_prev;
+  float c1[ODEHIP_MAX_STAGES + 1];
+  float c2[ODEHIP_MAX_STAGES + 1];
+  float k_scale;  // k_cur is multiplied by this first (-1 for backwards=True / reversed time)
+};
+
+struct ConvArgs {
+  const float* src1;
+  const float* src2;
+  const float* w_packed;
+  const float* bias;
+  const float* zero_page;
+  float* dst;
+  int q1;      // channel quads in src1
+  int qin;     // total input quads
+  int qout;    // output quads (cout / 4)
+  int batch;
+  int relu;
+  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue
+  CombineArgs cmb;
+};
+
+int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
+
+}  // namespace odehip

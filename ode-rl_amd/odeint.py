@@ -1,0 +1,103 @@
+"""`odeint(func, y0, t, rtol=, atol=, method=)` -- the call surface of torchdiffeq that the reference
+consumes (/root/reference/modules/DiffEqSolver.py:37,45-46), executed by the HIP library.
+
+Supported `func`: an `ODEFunc` (or any module exposing `gradient_net`, an nn.Sequential of stride-1
+'same' Conv2d layers separated by ReLU, as built by `helpers.utils.create_convnet`).  The dynamics are
+autonomous (`ODEFunc.forward` ignores t: modules/DiffEqSolver.py:77), so `t` only sets step sizes.
+
+Semantics follow torchdiffeq 0.2.1: solution[0] = y0, float64 time, 'rk4' = 3/8 rule with one step per
+output interval, strictly decreasing t integrates the negated dynamics on -t.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+
+FIXED_GRID = ("euler", "midpoint", "rk4")
+_t_cache = {}
+
+
+def _host_times(t):
+    """float64 host copy of t; cached per (storage, version) so a device-resident t syncs once."""
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.float64)
+    if t.dim() != 1:
+        raise AssertionError("`t` must be one dimensional")
+    if not t.is_cuda:
+        return t.detach().to(torch.float64)
+    key = (t.data_ptr(), t._version, t.numel(), t.dtype)
+    hit = _t_cache.get(key)
+    if hit is None:
+        if len(_t_cache) > 64:
+            _t_cache.clear()
+        hit = t.detach().to("cpu", torch.float64)
+        _t_cache[key] = hit
+    return hit
+
+
+def _check_monotone(t):
+    if len(t) > 1:
+        d = t[1:] - t[:-1]
+        if not (bool((d > 0).all()) or bool((d < 0).all())):
+            raise AssertionError("t must be strictly increasing or decreasing")
+
+
+def conv_stack_of(func):
+    """Find (and cache on the module) the packed conv stack behind an ODEFunc-like module."""
+    cached = getattr(func, "_hip_stack", None)
+    if cached is not None:
+        return cached
+    net = getattr(func, "gradient_net", None)
+    if net is None and isinstance(func, nn.Sequential):
+        net = func
+    if not isinstance(net, nn.Sequential):
+        raise TypeError("odeint(HIP): `func` must expose `gradient_net` (nn.Sequential of Conv2d/ReLU as built by "
+                        "create_convnet); arbitrary Python dynamics are not supported and there is no CPU fallback")
+    convs, final_tanh = [], False
+    mods = list(net)
+    for i, m in enumerate(mods):
+        if isinstance(m, nn.Conv2d):
+            convs.append(m)
+        elif isinstance(m, nn.ReLU):
+            continue
+        elif isinstance(m, nn.Tanh) and i == len(mods) - 1:
+            final_tanh = True
+        else:
+            raise TypeError(f"odeint(HIP): unsupported layer {m} in gradient_net (Conv2d/ReLU only)")
+    # create_convnet alternates conv, act, conv, ... : every conv but the last is followed by ReLU
+    for i, m in enumerate(mods[:-1]):
+        if isinstance(m, nn.Conv2d) and not isinstance(mods[i + 1], nn.ReLU):
+            raise TypeError("odeint(HIP): every hidden Conv2d must be followed by ReLU")
+    stack = hip_ops.PackedConvStack(convs, final_tanh)
+    try:
+        object.__setattr__(func, "_hip_stack", stack)
+    except Exception:
+        pass
+    return stack
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
+    if method is None:
+        method = "dopri5"
+    if method not in ("euler", "midpoint", "rk4", "dopri5"):
+        raise ValueError('Invalid method "{}". Must be one of euler, midpoint, rk4, dopri5'.format(method))
+    hip_ops.require_device_tensor(y0, "y0")
+    if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in func.parameters())):
+        from .autograd import odeint_with_grad
+        return odeint_with_grad(func, y0, t, rtol, atol, method)
+    return odeint_forward(func, y0, t, rtol, atol, method)
+
+
+def odeint_forward(func, y0, t, rtol, atol, method, negate=None):
+    th = _host_times(t)
+    _check_monotone(th)
+    backwards = bool(getattr(func, "_hip_backwards", False))
+    if len(th) > 1 and bool(th[0] > th[1]):
+        th = -th
+        backwards = not backwards
+    if backwards:
+        raise NotImplementedError("odeint(HIP): reversed-time integration is not implemented yet")
+    stack = conv_stack_of(func)
+    if method in FIXED_GRID:
+        return hip_ops.odeint_fixed(stack, method, y0, th)
+    raise NotImplementedError("odeint(HIP): dopri5 is not implemented yet")

@@ -1,0 +1,79 @@
+"""GPU parity of the single-layer HIP conv (odehip_conv_q4) against torch CPU fp32 conv2d.
+Tolerance: rel-L2 <= 2e-6 per layer (exact-fp32 MFMA vs oneDNN fp32; only summation order differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (batch, cin1, cin2, cout, ks, relu)
+    (3, 64, 0, 64, 3, True),
+    (2, 128, 0, 64, 3, False),
+    (1, 64, 0, 128, 3, True),
+    (2, 32, 0, 32, 3, False),
+    (5, 32, 32, 64, 5, False),
+    (2, 64, 64, 128, 5, True),
+    (2, 64, 0, 64, 1, True),
+    (2, 64, 0, 128, 1, False),
+    (1, 16, 0, 32, 3, False),
+]
+
+
+@pytest.mark.parametrize("b,cin1,cin2,cout,ks,relu", CASES)
+def test_conv_matches_torch(cuda, b, cin1, cin2, cout, ks, relu):
+    from ode_rl_amd import hip_ops
+    g = torch.Generator().manual_seed(b * 1000 + cin1 + cout + ks)
+    cin = cin1 + cin2
+    x = torch.randn(b, cin, 16, 16, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=ks // 2)
+    if relu:
+        ref = torch.relu(ref)
+    xd = x.to(cuda)
+    src1 = hip_ops.nchw_to_q4(xd[:, :cin1].contiguous())
+    src2 = hip_ops.nchw_to_q4(xd[:, cin1:].contiguous()) if cin2 else None
+    wp = hip_ops.pack_conv_weight(w.to(cuda))
+    out = hip_ops.q4_to_nchw(hip_ops.conv_q4(src1, wp, bias.to(cuda), cout, ks, src2=src2, relu=relu))
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) <= 2e-6
+
+
+def test_layout_roundtrip(cuda):
+    from ode_rl_amd import hip_ops
+    x = torch.randn(3, 64, 16, 16, device=cuda)
+    q = hip_ops.nchw_to_q4(x)
+    assert q.shape == (3, 16, 256, 4)
+    # Q4[b][c/4][p][c%4]
+    ref = x.view(3, 16, 4, 256).permute(0, 1, 3, 2).contiguous()
+    assert torch.equal(q, ref)
+    assert torch.equal(hip_ops.q4_to_nchw(q), x)
+
+
+def test_dgrad_weights_give_input_gradient(cuda):
+    """pack(transpose_flip) turns the same kernel into the input-gradient conv."""
+    from ode_rl_amd import hip_ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 16, 16, generator=g, requires_grad=True)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+    gy = torch.randn(2, 32, 16, 16, generator=g)
+    F.conv2d(x, w, None, padding=1).backward(gy)
+    wp = hip_ops.pack_conv_weight(w.to(cuda), transpose_flip=True)
+    out = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(gy.to(cuda)), wp, None, 64, 3))
+    assert rel_l2(out, x.grad) <= 2e-6
+
+
+def test_bad_shapes_raise(cuda):
+    from ode_rl_amd import hip_ops
+    x = hip_ops.nchw_to_q4(torch.randn(1, 64, 16, 16, device=cuda))
+    wp = torch.zeros(48 * 64 * 9, device=cuda)
+    with pytest.raises(ValueError):
+        hip_ops.conv_q4(x, wp, None, 48, 3)  # cout not a multiple of 32
+    with pytest.raises(ValueError):
+        hip_ops.conv_q4(x, wp, None, 64, 7)  # unsupported kernel size
+    with pytest.raises(RuntimeError):
+        hip_ops.nchw_to_q4(torch.randn(1, 64, 16, 16))  # CPU tensor: no fallback

@@ -1,0 +1,113 @@
+"""GPU parity of f(y) and of the fixed-grid trajectories against the oracle and the golden fixtures.
+
+Tolerances (fp32, stated per north_star): rel-L2 <= 1e-4 for trajectories (observed ~1e-6);
+f(y) alone <= 5e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2, state_dict_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _func_from_golden(gold, cuda, n_inputs, n_outputs, n_layers, n_units):
+    import ode_rl_amd
+    f = ode_rl_amd.ODEFunc(n_inputs=n_inputs, n_outputs=n_outputs, n_layers=n_layers, n_units=n_units,
+                           downsize=False, nonlinear="relu", final_act=False)
+    f.load_state_dict(state_dict_of(gold))
+    return f.to(cuda)
+
+
+def _oracle_f(gold):
+    from oracle import reference_modules as rm
+    ws, bs = rm.split_convnet_state(state_dict_of(gold), "gradient_net.")
+    return rm.ode_func(ws, bs)
+
+
+def test_f_A_matches_reference_fixture(cuda):
+    gold = load_golden("f_A.npz")
+    f = _func_from_golden(gold, cuda, 64, 64, 3, 64)
+    y = torch.from_numpy(gold["y"]).to(cuda)
+    with torch.no_grad():
+        out = f(0.0, y)
+        outb = f(0.0, y, backwards=True)
+    assert rel_l2(out, torch.from_numpy(gold["out"])) <= 5e-6
+    assert rel_l2(outb, torch.from_numpy(gold["out_backwards"])) <= 5e-6
+
+
+def test_f_V_matches_reference_fixture(cuda):
+    gold = load_golden("f_V.npz")
+    f = _func_from_golden(gold, cuda, 128, 128, 2, 64)
+    with torch.no_grad():
+        out = f(0.0, torch.from_numpy(gold["y"]).to(cuda))
+    assert rel_l2(out, torch.from_numpy(gold["out"])) <= 5e-6
+
+
+@pytest.mark.parametrize("method", ["rk4", "euler", "midpoint"])
+def test_fixed_grid_matches_golden_and_oracle(cuda, method):
+    import ode_rl_amd
+    from oracle import torchdiffeq_ref
+    fa = load_golden("f_A.npz")
+    tr = load_golden("traj_A.npz")
+    f = _func_from_golden(fa, cuda, 64, 64, 3, 64)
+    z0 = torch.from_numpy(tr["z0"])
+    t = torch.from_numpy(tr["t"])
+    solver = ode_rl_amd.DiffEqSolver(f, method, device=cuda)
+    with torch.no_grad():
+        sol = solver(z0.to(cuda), t.to(cuda))
+    assert sol.shape == (10, 2, 64, 16, 16)
+    assert torch.equal(sol[0].cpu(), z0)  # solution[0] = y0 exactly
+    assert rel_l2(sol[1], torch.from_numpy(tr[f"{method}.first"])) <= 1e-4
+    assert rel_l2(sol[-1], torch.from_numpy(tr[f"{method}.last"])) <= 1e-4
+    np.testing.assert_allclose(sol.flatten(1).norm(dim=1).cpu().numpy(), tr[f"{method}.norms"], rtol=1e-4)
+    with torch.no_grad():
+        ref = torchdiffeq_ref.odeint(_oracle_f(fa), z0, t, method=method)
+    assert rel_l2(sol, ref) <= 1e-4
+
+
+def test_rk4_uneven_grid_and_batch_odd(cuda):
+    """Ragged case: odd batch, non-uniform time grid, 2 time points, 1 time point."""
+    import ode_rl_amd
+    from oracle import torchdiffeq_ref
+    fa = load_golden("f_A.npz")
+    f = _func_from_golden(fa, cuda, 64, 64, 3, 64)
+    g = torch.Generator().manual_seed(5)
+    z0 = torch.randn(3, 64, 16, 16, generator=g) * 0.5
+    for t in (torch.tensor([0.0, 0.07, 0.1, 0.35], dtype=torch.float64), torch.tensor([0.2, 0.9], dtype=torch.float64),
+              torch.tensor([0.3], dtype=torch.float64)):
+        with torch.no_grad():
+            sol = ode_rl_amd.odeint(f, z0.to(cuda), t, method="rk4")
+            ref = torchdiffeq_ref.odeint(_oracle_f(fa), z0, t, method="rk4")
+        assert sol.shape == ref.shape
+        assert rel_l2(sol, ref) <= 1e-4
+
+
+def test_full_size_properties(cuda):
+    """BASELINE config 2 size (B=64, T=10): batch independence and determinism (size-independent properties)."""
+    import ode_rl_amd
+    torch.manual_seed(0)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
+    z0 = torch.randn(64, 64, 16, 16, generator=torch.Generator().manual_seed(1234)).to(cuda) * 0.5
+    t = torch.arange(10, 20, dtype=torch.float64) / 20
+    with torch.no_grad():
+        full = ode_rl_amd.odeint(f, z0, t, method="rk4")
+        again = ode_rl_amd.odeint(f, z0, t, method="rk4")
+        part = ode_rl_amd.odeint(f, z0[5:9].contiguous(), t, method="rk4")
+    assert torch.equal(full, again)                 # bitwise reproducible
+    assert torch.equal(full[:, 5:9], part)          # samples are independent (no cross-batch coupling)
+    assert torch.isfinite(full).all()
+
+
+def test_errors(cuda):
+    import ode_rl_amd
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
+    z0 = torch.zeros(1, 64, 16, 16, device=cuda)
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            ode_rl_amd.odeint(f, z0, torch.tensor([0.0, 1.0]), method="adams")
+        with pytest.raises(AssertionError):
+            ode_rl_amd.odeint(f, z0, torch.tensor([0.0, 0.5, 0.25]), method="rk4")
+        with pytest.raises(ValueError):
+            ode_rl_amd.odeint(f, torch.zeros(1, 32, 16, 16, device=cuda), torch.tensor([0.0, 1.0]), method="rk4")
