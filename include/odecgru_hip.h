@@ -42,6 +42,10 @@ enum { ODEHIP_EULER = 0, ODEHIP_MIDPOINT = 1, ODEHIP_RK4 = 2, ODEHIP_DOPRI5 = 3 
 
 const char* odehip_last_error(void);
 int odehip_version(void);
+/* diagnostic ablation bits for tools/conv_microbench.py (1 skip LDS-DMA, 2 skip MFMA, 4 skip epilogue); 0 in production */
+void odehip_set_debug_flags(int flags);
+/* device buffer of 8 x uint64 per workgroup for in-kernel stamps (flag 8); NULL disables */
+void odehip_set_debug_buffer(void* device_buffer);
 
 /* ---- layout + weight packing -------------------------------------------------------------- */
 
@@ -65,12 +69,13 @@ typedef struct odehip_conv_desc {
   int cin1, cin, cout, ks, batch;
   const float* w_packed;  /* from odehip_pack_conv_weight                                      */
   const float* bias;      /* cout floats or NULL                                               */
-  const float* zero_page; /* >= 1 KiB of zeros in device memory (row halo source)              */
   float* dst;             /* Q4 output                                                        */
   int relu;               /* fuse ReLU into the epilogue                                      */
 } odehip_conv_desc;
 
 int odehip_conv_q4(const odehip_conv_desc* d, void* stream);
+/* diagnostic: n back-to-back launches of the same layer (tools/conv_microbench.py) */
+int odehip_debug_repeat_conv(const odehip_conv_desc* d, int n, void* stream);
 
 /* ---- the dynamics f(t, y) = gradient_net(y)  (modules/DiffEqSolver.py:71-80) ---------------- */
 

@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
         ("src1", ctypes.c_void_p), ("src2", ctypes.c_void_p),
         ("cin1", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ks", ctypes.c_int),
         ("batch", ctypes.c_int),
-        ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("zero_page", ctypes.c_void_p),
+        ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("relu", ctypes.c_int),
     ]
 
@@ -48,12 +48,15 @@ _lib = None
 SIGNATURES = {
     "odehip_last_error": (ctypes.c_char_p, []),
     "odehip_version": (ctypes.c_int, []),
+    "odehip_set_debug_flags": (None, [ctypes.c_int]),
+    "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),
     "odehip_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "odehip_pack_conv_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_nchw_to_q4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_q4_to_nchw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_conv_q4": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "odehip_debug_repeat_conv": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]),
     "odehip_convstack_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int]),
     "odehip_convstack_forward": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,

@@ -77,7 +77,7 @@ static inline size_t state_bytes(int batch, int channels) { return (size_t)batch
 
 // Enqueue f(x) with the stage-combine fused into the last conv.  ping/pong hold hidden activations.
 static int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong,
-                     const float* zero_page, const CombineArgs* cmb, float* plain_dst, hipStream_t stream) {
+                     const CombineArgs* cmb, float* plain_dst, hipStream_t stream) {
   const float* cur = x_q4;
   for (int l = 0; l < f->n_convs; ++l) {
     const bool last = (l == f->n_convs - 1);
@@ -89,7 +89,6 @@ static int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, fl
     a.qout = f->channels[l + 1] / 4;
     a.w_packed = f->w_packed[l];
     a.bias = f->bias[l];
-    a.zero_page = zero_page;
     a.batch = batch;
     if (!last) {
       a.relu = 1;
@@ -114,6 +113,8 @@ using namespace odehip;
 
 extern "C" const char* odehip_last_error(void) { return g_err; }
 extern "C" int odehip_version(void) { return 1; }
+extern "C" void odehip_set_debug_flags(int flags) { g_debug_flags = flags; }
+extern "C" void odehip_set_debug_buffer(void* p) { g_debug_buf = (unsigned long long*)p; }
 
 extern "C" int odehip_conv_q4(const odehip_conv_desc* d, void* stream) {
   ODEHIP_REQUIRE(d, "conv_q4: null descriptor");
@@ -130,18 +131,26 @@ extern "C" int odehip_conv_q4(const odehip_conv_desc* d, void* stream) {
   a.qout = d->cout / 4;
   a.w_packed = d->w_packed;
   a.bias = d->bias;
-  a.zero_page = d->zero_page;
   a.dst = d->dst;
   a.batch = d->batch;
   a.relu = d->relu;
   return launch_conv(a, d->ks, (hipStream_t)stream);
 }
 
-// workspace of f(y): [zero page | x_q4 | ping | pong | out_q4]
+// diagnostic: n back-to-back launches from C (tools/conv_microbench.py), to take Python out of the loop
+extern "C" int odehip_debug_repeat_conv(const odehip_conv_desc* d, int n, void* stream) {
+  for (int i = 0; i < n; ++i) {
+    int rc = odehip_conv_q4(d, stream);
+    if (rc != ODEHIP_OK) return rc;
+  }
+  return ODEHIP_OK;
+}
+
+// workspace of f(y): [x_q4 | ping | pong | out_q4]
 extern "C" size_t odehip_convstack_workspace_bytes(const odehip_convstack* f, int batch) {
   if (!f || batch <= 0) return 0;
   const size_t hid = align_up(state_bytes(batch, max_hidden(f)), 256);
-  return 1024 + align_up(state_bytes(batch, f->channels[0]), 256) + 2 * hid +
+  return align_up(state_bytes(batch, f->channels[0]), 256) + 2 * hid +
          align_up(state_bytes(batch, f->channels[f->n_convs]), 256);
 }
 
@@ -154,25 +163,23 @@ extern "C" int odehip_convstack_forward(const odehip_convstack* f, const float* 
   ODEHIP_REQUIRE(workspace_bytes >= odehip_convstack_workspace_bytes(f, batch), "convstack_forward: workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
   Carver ws(workspace);
-  float* zero = ws.take(1024);
   float* x = ws.take(state_bytes(batch, f->channels[0]));
   float* ping = ws.take(state_bytes(batch, max_hidden(f)));
   float* pong = ws.take(state_bytes(batch, max_hidden(f)));
   float* out = ws.take(state_bytes(batch, f->channels[f->n_convs]));
-  ODEHIP_CHECK_HIP(hipMemsetAsync(zero, 0, 1024, stream));
   rc = odehip_nchw_to_q4(y_nchw, x, batch, f->channels[0], stream);
   if (rc != ODEHIP_OK) return rc;
   CombineArgs cmb;
   memset(&cmb, 0, sizeof(cmb));
   cmb.k_out = out;
   cmb.k_scale = negate ? -1.0f : 1.0f;
-  rc = enqueue_f(f, x, batch, ping, pong, zero, &cmb, nullptr, stream);
+  rc = enqueue_f(f, x, batch, ping, pong, &cmb, nullptr, stream);
   if (rc != ODEHIP_OK) return rc;
   return odehip_q4_to_nchw(out, out_nchw, batch, f->channels[f->n_convs], stream);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fixed-grid odeint.  Workspace: [zero page | h[n_times-1] | ping | pong | x_stage | k0..k2 | y_q4[n_times]]
+// Fixed-grid odeint.  Workspace: [h[n_times-1] | ping | pong | x_stage | k0..k2 | y_q4[n_times]]
 // ---------------------------------------------------------------------------------------------
 static int n_k_buffers(int method) { return method == ODEHIP_RK4 ? 3 : (method == ODEHIP_MIDPOINT ? 1 : 0); }
 
@@ -182,7 +189,7 @@ extern "C" size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int b
   (void)save_for_backward;
   const size_t st = align_up(state_bytes(batch, f->channels[0]), 256);
   const size_t hid = align_up(state_bytes(batch, max_hidden(f)), 256);
-  return 1024 + align_up((size_t)n_times * sizeof(float), 256) + 2 * hid + st + (size_t)n_k_buffers(method) * st +
+  return align_up((size_t)n_times * sizeof(float), 256) + 2 * hid + st + (size_t)n_k_buffers(method) * st +
          (size_t)n_times * st;
 }
 
@@ -209,7 +216,6 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   const size_t st_f = st / sizeof(float);
 
   Carver ws(workspace);
-  float* zero = ws.take(1024);
   float* hdev = ws.take((size_t)n_times * sizeof(float));
   float* ping = ws.take(state_bytes(batch, max_hidden(f)));
   float* pong = ws.take(state_bytes(batch, max_hidden(f)));
@@ -218,7 +224,6 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   for (int i = 0; i < n_k_buffers(method); ++i) k[i] = ws.take(st);
   float* yq = ws.take((size_t)n_times * st);
 
-  ODEHIP_CHECK_HIP(hipMemsetAsync(zero, 0, 1024, stream));
   // out[0] = z0 (torchdiffeq: solution[0] = y0)
   ODEHIP_CHECK_HIP(hipMemcpyAsync(out_nchw, z0_nchw, st, hipMemcpyDeviceToDevice, stream));
   rc = odehip_nchw_to_q4(z0_nchw, yq, batch, C, stream);
@@ -247,21 +252,21 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.c2[0] = 1.0f;
       c.out2 = ynew;
       c.out2_nchw = ynew_nchw;
-      rc = enqueue_f(f, y, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
     } else if (method == ODEHIP_MIDPOINT) {
       // x = y + h/2*k1 ; y1 = y + h*f(x)
       c.n_prev = 0;
       c.c1[0] = 0.5f;
       c.out1 = xs;
-      rc = enqueue_f(f, y, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       c.c1[0] = 0.0f;
       c.out1 = nullptr;
       c.c2[0] = 1.0f;
       c.out2 = ynew;
       c.out2_nchw = ynew_nchw;
-      rc = enqueue_f(f, xs, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
     } else {
       // 3/8 rule (torchdiffeq rk4_alt_step_func)
@@ -271,7 +276,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.k_out = k[0];
       c.c1[0] = third;
       c.out1 = xs;
-      rc = enqueue_f(f, y, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       // stage 2: k2 = f(x2); x3 = y + h*(k2 - k1/3)
       c.n_prev = 1;
@@ -279,7 +284,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.k_out = k[1];
       c.c1[0] = -third;
       c.c1[1] = 1.0f;
-      rc = enqueue_f(f, xs, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       // stage 3: k3 = f(x3); x4 = y + h*(k1 - k2 + k3)
       c.n_prev = 2;
@@ -288,7 +293,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.c1[0] = 1.0f;
       c.c1[1] = -1.0f;
       c.c1[2] = 1.0f;
-      rc = enqueue_f(f, xs, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       // stage 4: k4 = f(x4); y1 = y + h*(k1 + 3(k2+k3) + k4)/8
       c.n_prev = 3;
@@ -301,7 +306,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.c2[3] = 0.125f;
       c.out2 = ynew;
       c.out2_nchw = ynew_nchw;
-      rc = enqueue_f(f, xs, batch, ping, pong, zero, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
     }
   }

@@ -12,15 +12,20 @@
 //     16 accumulator registers, one chain).
 //   * activations live in HBM in the Q4 layout [b][c/4][y][x][4]: a channel quad of a pixel is
 //     16 contiguous bytes, an image row of a quad 256 B, so a wave-wide 1 KiB LDS-DMA piece is 4 image
-//     rows of one quad -- contiguous in HBM *and* lane-linear in LDS (global_load_lds needs that).
-//   * weights are pre-packed (pack_weights.hip) into the exact LDS image: per (8-channel group m, tap)
+//     rows of one quad -- contiguous in HBM *and* lane-linear in LDS (LDS-DMA needs that).
+//   * weights are pre-packed (layout.hip) into the exact LDS image: per (8-channel group m, tap)
 //     one 1 KiB piece [kq][co32][4].  Operand fragments are single ds_read_b128 reads, bank-conflict
 //     free for both operands (16 consecutive 16-B slots per 16-lane group).
-//   * K is streamed in chunks of 8*MC input channels through an NBUF-deep LDS ring filled by
-//     global_load_lds_dwordx4 (no VGPR staging) with counted s_waitcnt vmcnt(N) + raw s_barrier, so
-//     later chunks stay in flight while earlier ones are being multiplied.
-//   * image-row halo: out-of-image rows are DMA'd from a zero page (per-lane source address), so
-//     no LDS zero-fill pass; the x halo is handled by zeroing the B fragment of edge lanes.
+//   * operands reach LDS by `buffer_load_dwordx4 ... lds` (no VGPR staging): per-lane offset in a VGPR
+//     that never changes, piece offset in an SGPR, so a DMA costs two scalar instructions.  Image rows
+//     outside [0,16) are given an out-of-range offset: the buffer range check writes zeros to LDS, which
+//     is the conv's zero padding (measured: tools/experiments/buflds.hip).  The x halo is handled by
+//     zeroing the B fragment of edge lanes.
+//   * two kernels: `conv3x3_resident_kernel` (cin <= 64: the whole K extent, <= 120 KiB, is DMA'd up
+//     front and multiplied behind two counted waits) and `conv_ring_kernel` (any cin, 1x1/3x3/5x5: K is
+//     streamed in chunks through an NBUF-deep LDS ring with counted s_waitcnt vmcnt(N) + raw s_barrier).
+#include <type_traits>
+
 #include "odehip_internal.h"
 
 namespace odehip {
@@ -28,11 +33,264 @@ namespace odehip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define ODEHIP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define ODEHIP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+constexpr int kOobOffset = 0x7fff0000;  // beyond any buffer's num_records -> DMA writes zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  // raw buffer (stride 0), DATA_FORMAT=32 so that the range check is enabled: flags 0x00020000
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, ODEHIP_LDS_PTR(lds), 16, voffset, soffset, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ int xcd_block_id() {
+  // blocks p and p+8 share an XCD (round-robin dispatch; speed only, never correctness): give each XCD a
+  // contiguous range of logical ids so the workgroups of one sample hit the same L2.
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  return bid;
+}
+
+// 32 biases of the tile by two wave-uniform 64-B scalar loads; lane half kq picks its 16
+__device__ __forceinline__ f32x16 bias_init(const float* bias, int ct, int kq) {
+  f32x16 acc;
+  if (bias) {
+    const f32x16 lo16 = *(const f32x16*)(bias + ct * 32);
+    const f32x16 hi16 = *(const f32x16*)(bias + ct * 32 + 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c0 = (r & 3) + 8 * (r >> 2);  // 0..27, +4 for the upper lane half
+      const float lo = c0 < 16 ? lo16[c0 & 15] : hi16[c0 & 15];
+      const float hi = (c0 + 4) < 16 ? lo16[(c0 + 4) & 15] : hi16[(c0 + 4) & 15];
+      acc[r] = kq ? hi : lo;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  }
+  return acc;
+}
+
+// ---- epilogue: lane (pixel i32, half kq) holds channel quads 2g+kq of this 32-channel tile
+__device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, int b, int ct, int P, int kq) {
+  if (!a.combine) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      if (a.relu) {
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+      }
+      const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
+      *(f32x4*)(a.dst + off) = v;
+    }
+    return;
+  }
+  const CombineArgs& m = a.cmb;
+  const float h = m.h_ptr ? *m.h_ptr : 1.0f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int Q = ct * 8 + 2 * g + kq;
+    const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
+    f32x4 kc = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    kc *= m.k_scale;
+    if (m.k_out) *(f32x4*)(m.k_out + off) = kc;
+    if (m.y) {
+      const f32x4 yv = *(const f32x4*)(m.y + off);
+      f32x4 sa = kc * m.c1[m.n_prev];
+      f32x4 sb = kc * m.c2[m.n_prev];
+      for (int j = 0; j < m.n_prev; ++j) {
+        const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
+        sa += kp * m.c1[j];
+        sb += kp * m.c2[j];
+      }
+      if (m.out1) *(f32x4*)(m.out1 + off) = yv + sa * h;
+      const f32x4 o2 = yv + sb * h;
+      if (m.out2) *(f32x4*)(m.out2 + off) = o2;
+      if (m.out2_nchw) {
+        float* o = m.out2_nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
+        o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+      }
+    }
+  }
+}
+
+// diagnostic stamps (debug & 8): [0] start, [1] DMA issued, [2] chunk 0 landed, [3] MFMA done, [4] end in
+// 100 MHz ticks (s_memrealtime); [5..7] points 1..3 in shader cycles (s_memtime) relative to start
+struct Stamps {
+  unsigned long long rt[5] = {0, 0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+  bool on;
+  __device__ __forceinline__ explicit Stamps(const ConvArgs& a) : on((a.debug & 8) && threadIdx.x == 0) {}
+  __device__ __forceinline__ void take(int i) {
+    if (on) {
+      rt[i] = __builtin_amdgcn_s_memrealtime();
+      if (i < 4) cy[i] = __builtin_amdgcn_s_memtime();
+    }
+  }
+  __device__ __forceinline__ void flush(const ConvArgs& a) {
+    if (on) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      take(4);
+      unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
+      for (int i = 0; i < 5; ++i) o[i] = rt[i];
+      for (int i = 1; i < 4; ++i) o[4 + i] = cy[i] - cy[0];
+    }
+  }
+};
+
+__device__ __forceinline__ void mfma4(f32x16& acc, const f32x4& wv, const f32x4& xv) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc, 0, 0, 0);
+}
+
+// =================================================================================================
+// Resident 3x3 kernel: cin = 16*NCHUNK <= 64.  LDS stage c = [18 KiB weights of channels 16c..16c+15 |
+// 4 quads x 12 rows (3 pieces) of input], all NCHUNK stages DMA'd at kernel start (8 DMAs per wave
+// per stage: 5 weight pieces (waves 2,3 re-copy piece 17 once) + the 3 pieces of quad `wave`).
+// =================================================================================================
+template <int NCHUNK>
+__global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs a) {
+  constexpr int TAPS = 9, NP = 3, MC = 2;
+  constexpr int W_BYTES = MC * TAPS * 1024, IN_BYTES = 2 * MC * NP * 1024, STAGE = W_BYTES + IN_BYTES;
+  constexpr int G = 8;          // DMAs per wave per stage
+  constexpr int NG = MC * TAPS; // fragment groups (4 MFMAs each) per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Stamps st(a);
+  st.take(0);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bid = xcd_block_id();
+  const int ct_count = a.qout >> 3;
+  const int rh = bid & 1;
+  const int ct = (bid >> 1) % ct_count;
+  const int b = (bid >> 1) / ct_count;
+  const int r0 = rh * 8;
+  const bool dma = !(a.debug & 1), mfma = !(a.debug & 2);
+
+  const unsigned tile_w_bytes = (unsigned)NCHUNK * W_BYTES;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.w_packed + (size_t)ct * tile_w_bytes, tile_w_bytes);
+  const __amdgpu_buffer_rsrc_t rx =
+      make_rsrc((const char*)a.src1 + (size_t)b * a.qin * kQuadBytes, (unsigned)a.qin * kQuadBytes);
+  const int vw = lane * 16;
+  int vx[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int row = r0 - 1 + 4 * j + (lane >> 4);
+    vx[j] = (row >= 0 && row < kHW) ? row * 256 + (lane & 15) * 16 : kOobOffset;
+  }
+  // DMA number g (0..7) of stage c, for this wave: 5 weight pieces (waves 2,3 re-copy piece 17 once: same
+  // bytes) and the 3 row pieces of channel quad `wave` of the stage
+  auto issue_one = [&](int c, int g) {
+    char* stage = smem + c * STAGE;
+    if (g < 5) {
+      int p = g * 4 + wave;
+      p = p > MC * TAPS - 1 ? MC * TAPS - 1 : p;
+      dma16(rw, stage + p * 1024, vw, (c * MC * TAPS + p) * 1024);
+    } else {
+      const int j = g - 5;
+      dma16(rx, stage + W_BYTES + (wave * NP + j) * 1024, vx[j], (c * 2 * MC + wave) * kQuadBytes);
+    }
+  };
+  if (dma) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) issue_one(0, g);
+  }
+  st.take(1);
+
+  const int i32 = lane & 31;   // A row (co) / B col (pixel) of this lane
+  const int kq = lane >> 5;    // which half of an 8-channel group this lane feeds
+  // two accumulator chains: a dependent v_mfma_f32_32x32x2_f32 issues ~8 cycles later than an independent one
+  f32x16 acc0 = bias_init(a.bias, ct, kq), acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+  const int px = i32 & 15, pyl = i32 >> 4;
+  const char* wbase = smem + kq * 512 + i32 * 16;
+  const char* xbase = smem + W_BYTES + kq * NP * 1024 + (wave * 2 + pyl + 1) * 256 + px * 16;
+
+  // fragments of group gi = (mm, tap) of stage c; edge lanes of the x halo are zeroed by mask_x at use
+  auto load_frag = [&](int c, int gi, f32x4& wv, f32x4& xv) {
+    const int mm = gi / TAPS, tap = gi % TAPS;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    wv = *(const f32x4*)(wbase + c * STAGE + (mm * TAPS + tap) * 1024);
+    xv = *(const f32x4*)(xbase + c * STAGE + mm * 2 * NP * 1024 + dy * 256 + dx * 16);
+  };
+  const bool edge_l = px == 0, edge_r = px == 15;
+  auto mask_x = [&](int gi, f32x4& xv) {
+    const int dx = (gi % TAPS) % 3 - 1;
+    if (dx != 0) {
+      const bool kill = dx < 0 ? edge_l : edge_r;
+      xv.x = kill ? 0.0f : xv.x;
+      xv.y = kill ? 0.0f : xv.y;
+      xv.z = kill ? 0.0f : xv.z;
+      xv.w = kill ? 0.0f : xv.w;
+    }
+  };
+
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // stage c landed for every wave
+    if (c == 0) st.take(2);
+    if (mfma) {
+      // One scheduling region per group of 4 MFMAs: edge masks | MFMA | the 2 fragment reads of the NEXT
+      // group | MFMA | [one DMA of stage c+1, every other group] | 2 MFMA.  The reads get ~200 cycles of
+      // MFMA cover; the next stage lands behind this stage's MFMAs.
+      f32x4 wv, xv, wn, xn;
+      load_frag(c, 0, wv, xv);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        mask_x(gi, xv);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc0, 0, 0, 0);
+        if (gi + 1 < NG) load_frag(c, gi + 1, wn, xn);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc1, 0, 0, 0);
+        const bool with_dma = dma && c + 1 < NCHUNK && (gi & 1) == 0 && gi / 2 < G;
+        if (with_dma) issue_one(c + 1, gi / 2);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc1, 0, 0, 0);
+        wv = wn;
+        xv = xn;
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (with_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (dma && c + 1 < NCHUNK) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) issue_one(c + 1, g);
+    }
+  }
+  f32x16 acc = acc0 + acc1;
+  if (st.on) {
+    asm volatile("" ::"v"(acc[0]));
+    st.take(3);
+  }
+  if (a.debug & 4) {
+    if (acc[0] == 12345.678f) a.dst[0] = acc[1];  // keep the accumulators live
+    return;
+  }
+  epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq);
+  st.flush(a);
+}
+
+// =================================================================================================
+// Ring kernel: any cin (multiple of 8*MC), KS in {1,3,5}, optional second source (torch.cat(x, h)).
+// =================================================================================================
 template <int KS, int MC>
-struct ConvCfg {
+struct RingCfg {
   static constexpr int TAPS = KS * KS;
   static constexpr int HALO = KS / 2;
   static constexpr int NP = (KS == 1) ? 2 : 3;          // 1 KiB pieces (4 image rows) per channel quad
@@ -40,13 +298,8 @@ struct ConvCfg {
   static constexpr int IN_BYTES = 2 * MC * NP * 1024;   // input rows of one chunk
   static constexpr int STAGE_BYTES = W_BYTES + IN_BYTES;
   static constexpr int PIECES = STAGE_BYTES / 1024;
-  static constexpr int G = (PIECES + 3) / 4;            // global_load_lds per wave per chunk
+  static constexpr int G = (PIECES + 3) / 4;            // DMAs per wave per chunk
 };
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // waits until at most `younger` chunks (G loads each) issued after the awaited one are still in flight
 template <int G, int MAXY>
@@ -65,32 +318,37 @@ __device__ __forceinline__ void wait_chunk(int younger) {
 }
 
 template <int KS, int MC, int NBUF>
-__global__ __launch_bounds__(256, 1) void conv_q4_kernel(const ConvArgs a) {
-  using C = ConvCfg<KS, MC>;
+__global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
+  using C = RingCfg<KS, MC>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  Stamps st(a);
+  st.take(0);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-  // XCD-aware id: blocks p and p+8 share an XCD (round-robin dispatch, speed only); give each XCD a
-  // contiguous range of logical ids so the 2*CT workgroups of one sample hit the same L2.
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
-
+  const int bid = xcd_block_id();
   const int ct_count = a.qout >> 3;
   const int rh = bid & 1;
   const int ct = (bid >> 1) % ct_count;
   const int b = (bid >> 1) / ct_count;
   const int r0 = rh * 8;
-
   const int nchunk = a.qin / (2 * MC);
-  const char* wp_tile = (const char*)a.w_packed + (size_t)ct * a.qin / 2 * C::TAPS * 1024;
-  const char* s1 = (const char*)a.src1 + (size_t)b * a.q1 * kQuadBytes;
-  const char* s2 = a.src2 ? (const char*)a.src2 + (size_t)b * (a.qin - a.q1) * kQuadBytes : nullptr;
-  const char* zp = (const char*)a.zero_page + lane * 16;
-  const int lrow = lane >> 4;          // row of this lane inside a 4-row piece
-  const int lx16 = (lane & 15) * 16;   // byte offset of this lane's pixel inside a row
+  const bool dma = !(a.debug & 1), mfma = !(a.debug & 2);
+
+  const unsigned tile_w_bytes = (unsigned)(a.qin / 2) * C::TAPS * 1024;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.w_packed + (size_t)ct * tile_w_bytes, tile_w_bytes);
+  const __amdgpu_buffer_rsrc_t rx1 =
+      make_rsrc((const char*)a.src1 + (size_t)b * a.q1 * kQuadBytes, (unsigned)a.q1 * kQuadBytes);
+  const int q2n = a.qin - a.q1;
+  const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(
+      a.src2 ? (const char*)a.src2 + (size_t)b * q2n * kQuadBytes : (const char*)a.src1, (unsigned)q2n * kQuadBytes);
+  const int vw = lane * 16;
+  int vx[C::NP];
+#pragma unroll
+  for (int j = 0; j < C::NP; ++j) {
+    const int row = r0 - C::HALO + 4 * j + (lane >> 4);
+    vx[j] = (row >= 0 && row < kHW) ? row * 256 + (lane & 15) * 16 : kOobOffset;
+  }
 
   auto issue = [&](int c, int s) {
     char* stage = smem + s * C::STAGE_BYTES;
@@ -98,150 +356,147 @@ __global__ __launch_bounds__(256, 1) void conv_q4_kernel(const ConvArgs a) {
     for (int g = 0; g < C::G; ++g) {
       int p = g * 4 + wave;
       if (p > C::PIECES - 1) p = C::PIECES - 1;  // surplus slots re-copy the last piece (same bytes)
-      const char* src;
       if (p < MC * C::TAPS) {
-        src = wp_tile + ((size_t)c * MC * C::TAPS + p) * 1024 + lane * 16;
+        dma16(rw, stage + p * 1024, vw, (c * MC * C::TAPS + p) * 1024);
       } else {
         const int ip = p - MC * C::TAPS;
         const int ql = ip / C::NP, j = ip - ql * C::NP;
         const int q = c * 2 * MC + ql;
-        const int row = r0 - C::HALO + 4 * j + lrow;
-        const char* plane = (q < a.q1) ? s1 + (size_t)q * kQuadBytes : s2 + (size_t)(q - a.q1) * kQuadBytes;
-        src = (row >= 0 && row < kHW) ? plane + row * 256 + lx16 : zp;
+        int vo = vx[0];
+        if (C::NP > 1 && j == 1) vo = vx[1];
+        if (C::NP > 2 && j == 2) vo = vx[C::NP - 1];
+        if (q < a.q1) dma16(rx1, stage + p * 1024, vo, q * kQuadBytes);
+        else dma16(rx2, stage + p * 1024, vo, (q - a.q1) * kQuadBytes);
       }
-      __builtin_amdgcn_global_load_lds(ODEHIP_GLOBAL_PTR(src), ODEHIP_LDS_PTR(stage + p * 1024), 16, 0, 0);
     }
   };
 
-  // ---- accumulators start at the bias (D row = co, D col = pixel)
-  const int i32 = lane & 31;   // A row (co) / B col (pixel) of this lane
-  const int kq = lane >> 5;    // which half of the 8-channel group this lane feeds
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-    acc[r] = a.bias ? a.bias[co] : 0.0f;
-  }
-
+  const int i32 = lane & 31, kq = lane >> 5;
+  f32x16 acc = bias_init(a.bias, ct, kq);
   const int px = i32 & 15, pyl = i32 >> 4;
   const int a_off = kq * 512 + i32 * 16;
   const int b_off = kq * C::NP * 1024 + (wave * 2 + pyl + C::HALO) * 256 + px * 16;
 
-  auto compute = [&](int s) {
+  auto load_frag = [&](int s, int gi, f32x4& wv, f32x4& xv) {
     const char* wb = smem + s * C::STAGE_BYTES;
     const char* ib = wb + C::W_BYTES;
+    const int mm = gi / C::TAPS, tap = gi % C::TAPS;
+    const int dy = tap / KS - C::HALO, dx = tap % KS - C::HALO;
+    wv = *(const f32x4*)(wb + (mm * C::TAPS + tap) * 1024 + a_off);
+    xv = *(const f32x4*)(ib + mm * 2 * C::NP * 1024 + b_off + dy * 256 + dx * 16);
+    if (dx != 0) {
+      const bool ok = (dx < 0) ? (px + dx >= 0) : (px + dx <= 15);
+      xv.x = ok ? xv.x : 0.0f;
+      xv.y = ok ? xv.y : 0.0f;
+      xv.z = ok ? xv.z : 0.0f;
+      xv.w = ok ? xv.w : 0.0f;
+    }
+  };
+  auto compute = [&](int s) {
+    constexpr int NG = MC * C::TAPS;
+    f32x4 wv, xv, wn, xn;
+    load_frag(s, 0, wv, xv);
 #pragma unroll
-    for (int mm = 0; mm < MC; ++mm) {
-#pragma unroll
-      for (int tap = 0; tap < C::TAPS; ++tap) {
-        const int dy = tap / KS - C::HALO, dx = tap % KS - C::HALO;
-        const f32x4 wv = *(const f32x4*)(wb + (mm * C::TAPS + tap) * 1024 + a_off);
-        f32x4 xv = *(const f32x4*)(ib + mm * 2 * C::NP * 1024 + b_off + dy * 256 + dx * 16);
-        if (dx != 0) {
-          const bool ok = (dx < 0) ? (px + dx >= 0) : (px + dx <= 15);
-          xv.x = ok ? xv.x : 0.0f;
-          xv.y = ok ? xv.y : 0.0f;
-          xv.z = ok ? xv.z : 0.0f;
-          xv.w = ok ? xv.w : 0.0f;
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc, 0, 0, 0);
-      }
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG) load_frag(s, gi + 1, wn, xn);
+      mfma4(acc, wv, xv);
+      wv = wn;
+      xv = xn;
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     }
   };
 
   // ---- K pipeline: NBUF-deep ring, counted waits, one raw barrier per chunk
   const int pre = (NBUF - 1 < nchunk) ? NBUF - 1 : nchunk;
-  for (int c = 0; c < pre; ++c) issue(c, c);
+  if (dma)
+    for (int c = 0; c < pre; ++c) issue(c, c);
+  st.take(1);
   for (int c = 0; c < nchunk; ++c) {
     int issued = c + NBUF - 1;
     if (issued > nchunk) issued = nchunk;
     wait_chunk<C::G, NBUF - 2>(issued - (c + 1));
     __builtin_amdgcn_s_barrier();  // chunk c landed for every wave; every wave is done with chunk c-1
-    if (c + NBUF - 1 < nchunk) issue(c + NBUF - 1, (c + NBUF - 1) % NBUF);
-    compute(c % NBUF);
+    if (c == 0) st.take(2);
+    if (dma && c + NBUF - 1 < nchunk) issue(c + NBUF - 1, (c + NBUF - 1) % NBUF);
+    if (mfma) compute(c % NBUF);
   }
-
-  // ---- epilogue: lane (pixel i32, half kq) holds quads 2g+kq of this 32-channel tile
-  const int P = (r0 + wave * 2) * 16 + i32;
-  if (!a.combine) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      if (a.relu) {
-        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-      }
-      const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
-      *(f32x4*)(a.dst + off) = v;
-    }
-  } else {
-    const CombineArgs& m = a.cmb;
-    const float h = m.h_ptr ? *m.h_ptr : 1.0f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int Q = ct * 8 + 2 * g + kq;
-      const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
-      f32x4 kc = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      kc *= m.k_scale;
-      if (m.k_out) *(f32x4*)(m.k_out + off) = kc;
-      if (m.y) {
-        const f32x4 yv = *(const f32x4*)(m.y + off);
-        f32x4 sa = kc * m.c1[m.n_prev];
-        f32x4 sb = kc * m.c2[m.n_prev];
-        for (int j = 0; j < m.n_prev; ++j) {
-          const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
-          sa += kp * m.c1[j];
-          sb += kp * m.c2[j];
-        }
-        if (m.out1) *(f32x4*)(m.out1 + off) = yv + sa * h;
-        const f32x4 o2 = yv + sb * h;
-        if (m.out2) *(f32x4*)(m.out2 + off) = o2;
-        if (m.out2_nchw) {
-          float* o = m.out2_nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
-          o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
-        }
-      }
-    }
+  if (st.on) {
+    asm volatile("" ::"v"(acc[0]));
+    st.take(3);
   }
+  if (a.debug & 4) {
+    if (acc[0] == 12345.678f) a.dst[0] = acc[1];
+    return;
+  }
+  epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq);
+  st.flush(a);
 }
 
-template <int KS, int MC, int NBUF>
-static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
-  using C = ConvCfg<KS, MC>;
-  const int nchunk = a.qin / (2 * MC);
-  const int nbuf_alloc = (NBUF < nchunk) ? NBUF : nchunk;
-  const size_t lds = (size_t)nbuf_alloc * C::STAGE_BYTES + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv_q4_kernel<KS, MC, NBUF>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+// ---------------------------------------------------------------------------------------------- host
+template <typename K>
+static int launch_kernel(K kernel, const ConvArgs& a, size_t lds, hipStream_t stream, bool* attr_set) {
   ODEHIP_REQUIRE(lds <= 160 * 1024, "conv_q4: LDS request %zu exceeds 160 KiB", lds);
+  if (!*attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    *attr_set = true;
+  }
   const int grid = a.batch * (a.qout / 8) * 2;
-  hipLaunchKernelGGL((conv_q4_kernel<KS, MC, NBUF>), dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
 
-int launch_conv(const ConvArgs& a, int ks, hipStream_t stream) {
+template <int NCHUNK>
+static int launch_resident(const ConvArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  return launch_kernel(conv3x3_resident_kernel<NCHUNK>, a, (size_t)NCHUNK * 30 * 1024 + 64, stream, &attr_set);
+}
+
+template <int KS, int MC, int NBUF>
+static int launch_ring(const ConvArgs& a, hipStream_t stream) {
+  using C = RingCfg<KS, MC>;
+  static bool attr_set = false;
+  const int nchunk = a.qin / (2 * MC);
+  const int nbuf_alloc = (NBUF < nchunk) ? NBUF : nchunk;
+  return launch_kernel(conv_ring_kernel<KS, MC, NBUF>, a, (size_t)nbuf_alloc * C::STAGE_BYTES + 64, stream, &attr_set);
+}
+
+int g_debug_flags = 0;
+unsigned long long* g_debug_buf = nullptr;
+
+int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.debug = g_debug_flags;
+  a.dbg = g_debug_buf;
+  if (!a.dbg) a.debug &= ~8;
   ODEHIP_REQUIRE(a.batch > 0, "conv_q4: batch must be positive (got %d)", a.batch);
   ODEHIP_REQUIRE(a.qout > 0 && a.qout % 8 == 0, "conv_q4: cout must be a multiple of 32 (got %d)", a.qout * 4);
-  ODEHIP_REQUIRE(a.src1 && a.w_packed && a.zero_page, "conv_q4: null pointer argument");
+  ODEHIP_REQUIRE(a.src1 && a.w_packed, "conv_q4: null pointer argument");
   ODEHIP_REQUIRE(a.q1 > 0 && a.q1 <= a.qin && (a.q1 == a.qin || a.src2), "conv_q4: bad input split");
+  ODEHIP_REQUIRE((size_t)a.qin * kQuadBytes < (size_t)kOobOffset, "conv_q4: cin too large");
   if (ks == 3) {
     ODEHIP_REQUIRE(a.qin % 4 == 0, "conv_q4: 3x3 needs cin %% 16 == 0 (got %d)", a.qin * 4);
-    return launch_cfg<3, 2, 5>(a, stream);
+    if (a.q1 == a.qin && !(g_debug_flags & 16)) {
+      switch (a.qin / 4) {
+        case 1: return launch_resident<1>(a, stream);
+        case 2: return launch_resident<2>(a, stream);
+        case 3: return launch_resident<3>(a, stream);
+        case 4: return launch_resident<4>(a, stream);
+        default: break;
+      }
+    }
+    return launch_ring<3, 2, 5>(a, stream);
   }
   if (ks == 5) {
     ODEHIP_REQUIRE(a.qin % 2 == 0, "conv_q4: 5x5 needs cin %% 8 == 0 (got %d)", a.qin * 4);
-    return launch_cfg<5, 1, 4>(a, stream);
+    return launch_ring<5, 1, 4>(a, stream);
   }
   if (ks == 1) {
     ODEHIP_REQUIRE(a.qin % 4 == 0, "conv_q4: 1x1 needs cin %% 16 == 0 (got %d)", a.qin * 4);
-    return launch_cfg<1, 2, 4>(a, stream);
+    return launch_ring<1, 2, 4>(a, stream);
   }
   set_error("conv_q4: unsupported kernel size %d (1, 3, 5 supported)", ks);
   return ODEHIP_EINVAL;

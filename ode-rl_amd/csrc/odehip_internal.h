@@ -54,7 +54,6 @@ struct ConvArgs {
   const float* src2;
   const float* w_packed;
   const float* bias;
-  const float* zero_page;
   float* dst;
   int q1;      // channel quads in src1
   int qin;     // total input quads
@@ -62,9 +61,13 @@ struct ConvArgs {
   int batch;
   int relu;
   int combine; // 0: plain store (+relu); 1: CombineArgs epilogue
+  int debug;   // diagnostic ablation bits (tools/conv_microbench.py): 1 skip DMA, 2 skip MFMA, 4 skip epilogue
+  unsigned long long* dbg;  // debug & 8: per-workgroup stamps (8 x u64 per workgroup)
   CombineArgs cmb;
 };
 
 int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
+extern int g_debug_flags;
+extern unsigned long long* g_debug_buf;
 
 }  // namespace odehip

@@ -73,17 +73,6 @@ def pack_conv_weight(w, transpose_flip=False):
     return out
 
 
-_zero_pages = {}
-
-
-def zero_page(device):
-    z = _zero_pages.get(device)
-    if z is None:
-        z = torch.zeros(256, dtype=torch.float32, device=device)
-        _zero_pages[device] = z
-    return z
-
-
 def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False):
     """One conv layer on Q4 activations (tests / building block)."""
     require_device_tensor(src1, "src1")
@@ -94,7 +83,7 @@ def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False):
     d = _lib.ConvDesc(src1=src1.data_ptr(), src2=src2.data_ptr() if src2 is not None else None, cin1=cin1, cin=cin,
                       cout=cout, ks=ks, batch=b, w_packed=w_packed.data_ptr(),
                       bias=bias.data_ptr() if bias is not None else None,
-                      zero_page=zero_page(src1.device).data_ptr(), dst=dst.data_ptr(), relu=int(relu))
+                      dst=dst.data_ptr(), relu=int(relu))
     _lib.check(_lib.load().odehip_conv_q4(ctypes.byref(d), _stream()))
     return dst
 
