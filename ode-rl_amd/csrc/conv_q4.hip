@@ -123,25 +123,25 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
   }
 }
 
-// diagnostic stamps (debug & 8): [0] start, [1] DMA issued, [2] chunk 0 landed, [3] MFMA done, [4] end in
-// 100 MHz ticks (s_memrealtime); [5..7] points 1..3 in shader cycles (s_memtime) relative to start
+// diagnostic stamps (debug & 8), shader cycles (s_memtime) relative to the workgroup's start:
+// [1] first DMAs issued, [2] stage 0 landed, [3..6] end of stage 0..3 MFMAs, [7] end; [0] = start in 100 MHz ticks
 struct Stamps {
-  unsigned long long rt[5] = {0, 0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+  unsigned long long cy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0 = 0;
   bool on;
   __device__ __forceinline__ explicit Stamps(const ConvArgs& a) : on((a.debug & 8) && threadIdx.x == 0) {}
   __device__ __forceinline__ void take(int i) {
     if (on) {
-      rt[i] = __builtin_amdgcn_s_memrealtime();
-      if (i < 4) cy[i] = __builtin_amdgcn_s_memtime();
+      cy[i] = __builtin_amdgcn_s_memtime();
+      if (i == 0) rt0 = __builtin_amdgcn_s_memrealtime();
     }
   }
   __device__ __forceinline__ void flush(const ConvArgs& a) {
     if (on) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      take(4);
+      take(7);
       unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
-      for (int i = 0; i < 5; ++i) o[i] = rt[i];
-      for (int i = 1; i < 4; ++i) o[4 + i] = cy[i] - cy[0];
+      o[0] = rt0;
+      for (int i = 1; i < 8; ++i) o[i] = cy[i] ? cy[i] - cy[0] : 0;
     }
   }
 };
@@ -158,15 +158,16 @@ __device__ __forceinline__ void mfma4(f32x16& acc, const f32x4& wv, const f32x4&
 // 4 quads x 12 rows (3 pieces) of input], all NCHUNK stages DMA'd at kernel start (8 DMAs per wave
 // per stage: 5 weight pieces (waves 2,3 re-copy piece 17 once) + the 3 pieces of quad `wave`).
 // =================================================================================================
-template <int NCHUNK>
+template <int NCHUNK, bool DBG>
 __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs a) {
   constexpr int TAPS = 9, NP = 3, MC = 2;
   constexpr int W_BYTES = MC * TAPS * 1024, IN_BYTES = 2 * MC * NP * 1024, STAGE = W_BYTES + IN_BYTES;
   constexpr int G = 8;          // DMAs per wave per stage
   constexpr int NG = MC * TAPS; // fragment groups (4 MFMAs each) per stage
+  constexpr int ZERO_OFF = NCHUNK * STAGE;  // 2 KiB of zeros: where edge lanes read their x halo
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Stamps st(a);
-  st.take(0);
+  if (DBG) st.take(0);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs
   const int ct = (bid >> 1) % ct_count;
   const int b = (bid >> 1) / ct_count;
   const int r0 = rh * 8;
-  const bool dma = !(a.debug & 1), mfma = !(a.debug & 2);
+  const bool dma = !DBG || !(a.debug & 1), mfma = !DBG || !(a.debug & 2);
 
   const unsigned tile_w_bytes = (unsigned)NCHUNK * W_BYTES;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.w_packed + (size_t)ct * tile_w_bytes, tile_w_bytes);
@@ -206,84 +207,98 @@ __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs
 #pragma unroll
     for (int g = 0; g < G; ++g) issue_one(0, g);
   }
-  st.take(1);
+  if (DBG) st.take(1);
+  // the zero page of the x halo (read by edge lanes instead of the wrapped neighbour pixel)
+  *(f32x4*)(smem + ZERO_OFF + (threadIdx.x >> 1) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int i32 = lane & 31;   // A row (co) / B col (pixel) of this lane
   const int kq = lane >> 5;    // which half of an 8-channel group this lane feeds
-  // two accumulator chains: a dependent v_mfma_f32_32x32x2_f32 issues ~8 cycles later than an independent one
+  // two accumulator chains (even / odd channels of each quad)
   f32x16 acc0 = bias_init(a.bias, ct, kq), acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
   const int px = i32 & 15, pyl = i32 >> 4;
-  const char* wbase = smem + kq * 512 + i32 * 16;
-  const char* xbase = smem + W_BYTES + kq * NP * 1024 + (wave * 2 + pyl + 1) * 256 + px * 16;
+  const int w_lane = kq * 512 + i32 * 16;
+  const int x_lane = W_BYTES + kq * NP * 1024 + (wave * 2 + pyl + 1) * 256 + px * 16;
 
-  // fragments of group gi = (mm, tap) of stage c; edge lanes of the x halo are zeroed by mask_x at use
-  auto load_frag = [&](int c, int gi, f32x4& wv, f32x4& xv) {
-    const int mm = gi / TAPS, tap = gi % TAPS;
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    wv = *(const f32x4*)(wbase + c * STAGE + (mm * TAPS + tap) * 1024);
-    xv = *(const f32x4*)(xbase + c * STAGE + mm * 2 * NP * 1024 + dy * 256 + dx * 16);
-  };
-  const bool edge_l = px == 0, edge_r = px == 15;
-  auto mask_x = [&](int gi, f32x4& xv) {
-    const int dx = (gi % TAPS) % 3 - 1;
-    if (dx != 0) {
-      const bool kill = dx < 0 ? edge_l : edge_r;
-      xv.x = kill ? 0.0f : xv.x;
-      xv.y = kill ? 0.0f : xv.y;
-      xv.z = kill ? 0.0f : xv.z;
-      xv.w = kill ? 0.0f : xv.w;
-    }
-  };
-
+  // Per-stage base addresses so that every fragment read is base + 16-bit immediate.  For the dx = -1 / +1 taps
+  // the edge lanes (px = 0 / 15) are pointed at the zero page: no masking in the MFMA stream.  The x bases are
+  // biased by -272 so that the tap offsets (dy+1)*256 + (dx+1)*16 are non-negative immediates.
+  int wb[NCHUNK], xc[NCHUNK][MC], xl[NCHUNK][MC], xr[NCHUNK][MC];
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // stage c landed for every wave
-    if (c == 0) st.take(2);
-    if (mfma) {
-      // One scheduling region per group of 4 MFMAs: edge masks | MFMA | the 2 fragment reads of the NEXT
-      // group | MFMA | [one DMA of stage c+1, every other group] | 2 MFMA.  The reads get ~200 cycles of
-      // MFMA cover; the next stage lands behind this stage's MFMAs.
-      f32x4 wv, xv, wn, xn;
-      load_frag(c, 0, wv, xv);
+    wb[c] = c * STAGE + w_lane;
+    asm volatile("" : "+v"(wb[c]));
 #pragma unroll
-      for (int gi = 0; gi < NG; ++gi) {
-        mask_x(gi, xv);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc0, 0, 0, 0);
-        if (gi + 1 < NG) load_frag(c, gi + 1, wn, xn);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc1, 0, 0, 0);
-        const bool with_dma = dma && c + 1 < NCHUNK && (gi & 1) == 0 && gi / 2 < G;
-        if (with_dma) issue_one(c + 1, gi / 2);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc1, 0, 0, 0);
-        wv = wn;
-        xv = xn;
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (with_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else if (dma && c + 1 < NCHUNK) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) issue_one(c + 1, g);
+    for (int mm = 0; mm < MC; ++mm) {
+      xc[c][mm] = c * STAGE + x_lane + mm * 2 * NP * 1024 - 272;
+      xl[c][mm] = px == 0 ? ZERO_OFF + 1024 - 272 : xc[c][mm];
+      xr[c][mm] = px == 15 ? ZERO_OFF + 1024 - 272 : xc[c][mm];
+      asm volatile("" : "+v"(xc[c][mm]), "+v"(xl[c][mm]), "+v"(xr[c][mm]));
     }
   }
-  f32x16 acc = acc0 + acc1;
-  if (st.on) {
-    asm volatile("" ::"v"(acc[0]));
-    st.take(3);
+  // fragments of flat group index fg = stage * NG + (mm, tap)
+  auto load_frag = [&](int fg, f32x4& wv, f32x4& xv) {
+    const int c = fg / NG, gi = fg % NG;
+    const int mm = gi / TAPS, tap = gi % TAPS;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    wv = *(const f32x4*)(smem + wb[c] + (mm * TAPS + tap) * 1024);
+    const int xb = dx < 0 ? xl[c][mm] : (dx > 0 ? xr[c][mm] : xc[c][mm]);
+    xv = *(const f32x4*)(smem + xb + (dy + 1) * 256 + (dx + 1) * 16);
+  };
+
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();  // stage 0 and the zero page are visible to every wave
+  if (DBG) st.take(2);
+  if (mfma) {
+    // One software pipeline over all NCHUNK*NG groups of 4 MFMAs; one scheduling region per group:
+    //   MFMA | the 2 fragment reads of the NEXT group | MFMA | [one DMA of the next stage] | 2 MFMA
+    // so the reads get ~200 cycles of MFMA cover.  The DMAs of stage c+1 are issued in the first G groups of
+    // stage c and awaited (vmcnt(0) + barrier) two groups before stage c ends, so the pipeline never drains.
+    f32x4 wv, xv, wn, xn;
+    load_frag(0, wv, xv);
+#pragma unroll
+    for (int fg = 0; fg < NCHUNK * NG; ++fg) {
+      const int c = fg / NG, gi = fg % NG;
+      if (gi == NG - 2 && c + 1 < NCHUNK) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // stage c+1 landed for every wave
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc0, 0, 0, 0);
+      if (fg + 1 < NCHUNK * NG) load_frag(fg + 1, wn, xn);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc1, 0, 0, 0);
+      const bool with_dma = c + 1 < NCHUNK && gi < G;
+      if (with_dma && dma) issue_one(c + 1, gi);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc1, 0, 0, 0);
+      wv = wn;
+      xv = xn;
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (with_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG && gi == NG - 1 && st.on) {
+        asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]));
+        st.take(3 + c);
+      }
+    }
+  } else if (dma) {
+#pragma unroll
+    for (int c = 1; c < NCHUNK; ++c) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) issue_one(c, g);
+    }
+    wait_vmcnt<0>();
   }
-  if (a.debug & 4) {
+  f32x16 acc = acc0 + acc1;
+  if (DBG && (a.debug & 4)) {
     if (acc[0] == 12345.678f) a.dst[0] = acc[1];  // keep the accumulators live
     return;
   }
   epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq);
-  st.flush(a);
+  if (DBG) st.flush(a);
 }
 
 // =================================================================================================
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
   }
   if (st.on) {
     asm volatile("" ::"v"(acc[0]));
-    st.take(3);
+    st.take(6);
   }
   if (a.debug & 4) {
     if (acc[0] == 12345.678f) a.dst[0] = acc[1];
@@ -451,8 +466,10 @@ static int launch_kernel(K kernel, const ConvArgs& a, size_t lds, hipStream_t st
 
 template <int NCHUNK>
 static int launch_resident(const ConvArgs& a, hipStream_t stream) {
-  static bool attr_set = false;
-  return launch_kernel(conv3x3_resident_kernel<NCHUNK>, a, (size_t)NCHUNK * 30 * 1024 + 64, stream, &attr_set);
+  static bool attr_set = false, attr_set_dbg = false;
+  const size_t lds = (size_t)NCHUNK * 30 * 1024 + 2048;
+  if (a.debug) return launch_kernel(conv3x3_resident_kernel<NCHUNK, true>, a, lds, stream, &attr_set_dbg);
+  return launch_kernel(conv3x3_resident_kernel<NCHUNK, false>, a, lds, stream, &attr_set);
 }
 
 template <int KS, int MC, int NBUF>

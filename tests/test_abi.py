@@ -1,0 +1,71 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/odecgru_hip.h declares, with the
+ctypes table in ode-rl_amd/_lib.py in step with the header (no compute calls here: no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "odecgru_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(odehip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(ode_rl_amd._lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.odehip_version() >= 1
+    assert lib.odehip_packed_weight_floats(64, 64, 3) == 64 * 64 * 9
+
+
+def test_struct_layouts_match_header():
+    import ode_rl_amd
+    L = ode_rl_amd._lib
+    # odehip_conv_desc: 2 pointers, 5 ints (+pad), 3 pointers, 1 int (+pad)
+    assert ctypes.sizeof(L.ConvDesc) == 8 * 2 + 4 * 5 + 4 + 8 * 3 + 8
+    assert ctypes.sizeof(L.ConvStack) == 4 * 2 + 4 * 9 + 4 + 8 * 8 + 8 * 8 + 8
+    assert L.MAX_LAYERS == 8 and L.MAX_STAGES == 7
+
+
+def test_argument_errors_without_gpu():
+    """Argument validation runs before any HIP call, so it is checkable on the CPU box."""
+    import ode_rl_amd
+    L = ode_rl_amd._lib
+    lib = L.load()
+    assert lib.odehip_pack_conv_weight(None, None, 64, 64, 3, 0, None) == -1
+    assert b"null" in lib.odehip_last_error()
+    rc = lib.odehip_pack_conv_weight(ctypes.c_void_p(16), ctypes.c_void_p(16), 48, 64, 3, 0, None)
+    assert rc == -1 and b"multiple of 32" in lib.odehip_last_error()
+    with pytest.raises(ValueError):
+        L.check(rc)
+
+
+def test_no_cpu_fallback():
+    import ode_rl_amd
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        f(0.0, torch.zeros(1, 64, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ode_rl_amd.odeint(f, torch.zeros(1, 64, 16, 16), torch.tensor([0.0, 1.0]), method="rk4")
+
+
+def test_state_dict_layout_matches_reference_fixture():
+    """Drop-in: same parameter names/shapes as the reference's ODEFunc (keys captured in the fixture)."""
+    import numpy as np
+    import ode_rl_amd
+    with np.load(os.path.join(ROOT, "tests", "golden", "f_A.npz")) as z:
+        ref = {k[3:]: z[k].shape for k in z.files if k.startswith("sd.")}
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    assert {k: tuple(v.shape) for k, v in f.state_dict().items()} == ref

@@ -1,0 +1,153 @@
+"""Known-answer tests that pin the torchdiffeq-0.2.1 restatement (oracle/torchdiffeq_ref.py) WITHOUT the
+reference: the package is un-vendored and not installed, so these are what stands between a mis-recalled
+coefficient and silent drift (section 8c F8)."""
+import math
+
+import numpy as np
+import pytest
+import scipy.integrate
+import scipy.linalg
+import torch
+
+from oracle import torchdiffeq_ref as td
+
+
+def test_tableau_matches_scipy_rk45():
+    rk = scipy.integrate.RK45
+    np.testing.assert_allclose(td.DP_ALPHA, list(rk.C[1:]) + [1.0], rtol=0, atol=1e-15)
+    for i, row in enumerate(td.DP_BETA[:-1]):
+        np.testing.assert_allclose(row, rk.A[i + 1][:i + 1], rtol=1e-15)
+    np.testing.assert_allclose(td.DP_BETA[-1], rk.B, rtol=1e-15)
+    np.testing.assert_allclose(td.DP_C_SOL[:-1], rk.B, rtol=1e-15)
+    assert td.DP_C_SOL[-1] == 0.0
+    # Shampine's scaled error weights: c_error = 2/3 * (-E) in all 7 entries
+    np.testing.assert_allclose(td.DP_C_ERROR, (-2.0 / 3.0) * np.asarray(rk.E), rtol=1e-12, atol=1e-17)
+    # rows of the tableau sum to the node
+    for a, row in zip(td.DP_ALPHA, td.DP_BETA):
+        assert abs(sum(row) - a) < 1e-15
+    # the mid-point weights sum to 1/2
+    assert abs(sum(td.DP_C_MID) - 0.5) < 1e-15
+
+
+def _linear(A):
+    return lambda t, y: y @ A.T
+
+
+def test_rk4_is_the_three_eighths_rule_not_classic():
+    # y' = y^2 (non-linear, scalar) separates the 3/8 rule from classic RK4 at O(h^5)
+    f = lambda t, y: y * y
+    y0 = torch.tensor([1.0], dtype=torch.float64)
+    h = 0.1
+    t = torch.tensor([0.0, h], dtype=torch.float64)
+    got = float(td.odeint(f, y0, t, method="rk4")[1])
+
+    def step(y, kind):
+        if kind == "38":
+            k1 = y * y
+            k2 = (y + h * k1 / 3) ** 2
+            k3 = (y + h * (k2 - k1 / 3)) ** 2
+            k4 = (y + h * (k1 - k2 + k3)) ** 2
+            return y + h * (k1 + 3 * (k2 + k3) + k4) / 8
+        k1 = y * y
+        k2 = (y + h * k1 / 2) ** 2
+        k3 = (y + h * k2 / 2) ** 2
+        k4 = (y + h * k3) ** 2
+        return y + h * (k1 + 2 * k2 + 2 * k3 + k4) / 6
+    assert abs(got - step(1.0, "38")) < 1e-15
+    assert abs(got - step(1.0, "classic")) > 1e-9
+
+
+def test_fixed_grid_stability_polynomials():
+    # one step on y' = A y equals R(hA) y with R the method's stability polynomial
+    A = torch.tensor([[-0.3, 1.1], [-0.7, -0.2]], dtype=torch.float64)
+    y0 = torch.tensor([[0.4, -1.3]], dtype=torch.float64)
+    h = 0.25
+    t = torch.tensor([1.0, 1.0 + h], dtype=torch.float64)
+    Z = h * A
+    I = torch.eye(2, dtype=torch.float64)
+    R = {"euler": I + Z, "midpoint": I + Z + Z @ Z / 2,
+         "rk4": I + Z + Z @ Z / 2 + Z @ Z @ Z / 6 + Z @ Z @ Z @ Z / 24}
+    for m, Rm in R.items():
+        got = td.odeint(_linear(A), y0, t, method=m)[1]
+        torch.testing.assert_close(got, y0 @ Rm.T, rtol=1e-13, atol=1e-15)
+
+
+def test_solution0_is_y0_and_shapes():
+    A = torch.tensor([[-0.5]], dtype=torch.float64)
+    y0 = torch.randn(3, 1, dtype=torch.float64)
+    for m in ("euler", "midpoint", "rk4", "dopri5"):
+        sol = td.odeint(_linear(A), y0, torch.tensor([0.0, 0.3, 0.9], dtype=torch.float64), method=m)
+        assert sol.shape == (3, 3, 1) and torch.equal(sol[0], y0)
+        one = td.odeint(_linear(A), y0, torch.tensor([0.7], dtype=torch.float64), method=m)
+        assert one.shape == (1, 3, 1) and torch.equal(one[0], y0)
+    with pytest.raises(ValueError):
+        td.odeint(_linear(A), y0, torch.tensor([0.0, 1.0]), method="adams")
+    with pytest.raises(AssertionError):
+        td.odeint(_linear(A), y0, torch.tensor([0.0, 1.0, 0.5]), method="rk4")
+
+
+def test_dopri5_matches_expm_and_scipy():
+    A = torch.tensor([[-0.5, 2.0], [-2.0, -0.5]], dtype=torch.float64)
+    y0 = torch.tensor([[1.0, 0.5]], dtype=torch.float64)
+    t = torch.linspace(0.0, 2.0, 7, dtype=torch.float64)
+    st = {}
+    sol = td.odeint(_linear(A), y0, t, rtol=1e-9, atol=1e-11, method="dopri5", stats=st)
+    for i, ti in enumerate(t):
+        exact = torch.from_numpy(scipy.linalg.expm(A.numpy() * float(ti))) @ y0[0]
+        torch.testing.assert_close(sol[i, 0], exact, rtol=1e-7, atol=1e-9)
+    assert st["nfe"] == 2 + 6 * (st.get("n_accept", 0) + st.get("n_reject", 0))
+    # non-linear: van der Pol against scipy at tight tolerance
+    mu = 1.5
+    f = lambda t, y: torch.stack([y[1], mu * (1 - y[0] ** 2) * y[1] - y[0]])
+    ref = scipy.integrate.solve_ivp(lambda t, y: [y[1], mu * (1 - y[0] ** 2) * y[1] - y[0]], (0, 3), [2.0, 0.0],
+                                    rtol=1e-11, atol=1e-13, t_eval=[1.0, 2.0, 3.0]).y.T
+    sol = td.odeint(f, torch.tensor([2.0, 0.0], dtype=torch.float64), torch.tensor([0.0, 1.0, 2.0, 3.0], dtype=torch.float64),
+                    rtol=1e-8, atol=1e-10, method="dopri5")
+    np.testing.assert_allclose(sol[1:].numpy(), ref, rtol=2e-6, atol=2e-7)
+
+
+def test_dopri5_controller_pieces():
+    one = torch.tensor(0.1, dtype=torch.float64)
+    assert float(td._optimal_step_size(one, torch.tensor(0.0))) == pytest.approx(1.0)           # ratio 0 -> x10
+    assert float(td._optimal_step_size(one, torch.tensor(1e-12))) == pytest.approx(1.0)        # capped at ifactor
+    assert float(td._optimal_step_size(one, torch.tensor(1.0))) == pytest.approx(0.09)         # safety
+    assert float(td._optimal_step_size(one, torch.tensor(1e12))) == pytest.approx(0.02)        # floored at dfactor
+    assert float(td._optimal_step_size(one, torch.tensor(0.5))) == pytest.approx(0.1 * 0.9 / 0.5 ** 0.2)
+    # dense output: the quartic reproduces both ends and the mid-point formula
+    f = lambda t, y: -y
+    y0 = torch.tensor([1.0], dtype=torch.float64)
+    t0, dt = torch.tensor(0.0, dtype=torch.float64), torch.tensor(0.2, dtype=torch.float64)
+    y1, f1, err, k = td._rk_step(f, y0, f(t0, y0), t0, dt, t0 + dt)
+    co = td._interp_fit(y0, y1, k, dt)
+    torch.testing.assert_close(td._interp_evaluate(co, t0, t0 + dt, t0), y0)
+    torch.testing.assert_close(td._interp_evaluate(co, t0, t0 + dt, t0 + dt), y1, rtol=1e-13, atol=0)
+    mid = float(td._interp_evaluate(co, t0, t0 + dt, t0 + dt / 2))
+    assert abs(mid - math.exp(-0.1)) < 5e-7  # 4th-order dense output, h = 0.2
+
+
+def test_reversed_time_negates_dynamics():
+    A = torch.tensor([[-0.5, 1.0], [-1.0, -0.5]], dtype=torch.float64)
+    y0 = torch.tensor([[1.0, 0.0]], dtype=torch.float64)
+    fwd = td.odeint(_linear(A), y0, torch.tensor([0.0, 0.5, 1.0], dtype=torch.float64), rtol=1e-10, atol=1e-12, method="dopri5")
+    back = td.odeint(_linear(A), fwd[-1], torch.tensor([1.0, 0.5, 0.0], dtype=torch.float64), rtol=1e-10, atol=1e-12,
+                     method="dopri5")
+    torch.testing.assert_close(back[-1], y0, rtol=1e-7, atol=1e-9)
+    torch.testing.assert_close(back[1], fwd[1], rtol=1e-7, atol=1e-9)
+
+
+def test_adjoint_matches_autograd_through_the_solver():
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(3, 3).double()
+    f = lambda t, y: torch.tanh(lin(y))
+    y0 = torch.randn(2, 3, dtype=torch.float64)
+    t = torch.tensor([0.0, 0.4, 1.0], dtype=torch.float64)
+    gout = torch.randn(3, 2, 3, dtype=torch.float64)
+    # discretise-then-optimise gradient (what the reference does: autograd through the solver ops)
+    y0r = y0.clone().requires_grad_(True)
+    sol = td.odeint(f, y0r, t, rtol=1e-10, atol=1e-12, method="dopri5")
+    g = torch.autograd.grad(sol, [y0r] + list(lin.parameters()), gout)
+    ys, gy0, gp = td.odeint_adjoint(f, y0, t, list(lin.parameters()), gout, rtol=1e-10, atol=1e-12, method="dopri5")
+    torch.testing.assert_close(ys, sol.detach(), rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(gy0, g[0], rtol=1e-6, atol=1e-8)
+    for a, b in zip(gp, g[1:]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)

@@ -45,14 +45,10 @@ torch.cuda.synchronize()
 lib.odehip_set_debug_flags(0)
 lib.odehip_set_debug_buffer(None)
 s = dbg.view(-1, 8).cpu().double()
-t0 = s[:, 0].min()
-rt = (s[:, :5] - t0) * 0.01  # us since the first workgroup started
-print("per-workgroup stamps of the last launch (us since first WG start): median [min..max]")
-for i, n in enumerate(["start", "dma issued", "chunk0 landed", "mfma done", "end"]):
-    print(f"  {n:>14}: {rt[:, i].median():6.2f} [{rt[:, i].min():6.2f} .. {rt[:, i].max():6.2f}]")
-cy = s[:, 5:8]
-print("  shader cycles from start: dma issued %.0f, chunk0 landed %.0f, mfma done %.0f (median)" %
-      tuple(cy.median(dim=0).values.tolist()))
-mf_us = (rt[:, 3] - rt[:, 2]).median()
-mf_cy = (cy[:, 2] - cy[:, 1]).median()
-print(f"  mfma phase: {mf_us:.2f} us, {mf_cy:.0f} cycles -> {mf_cy / mf_us / 1e3:.2f} GHz; ideal 18432 cycles")
+names = ["(start, 100MHz ticks)", "first DMAs issued", "stage 0 landed", "stage 0 MFMAs done", "stage 1 MFMAs done",
+         "stage 2 MFMAs done", "stage 3 MFMAs done", "end (stores drained)"]
+print("per-workgroup stamps of the last launch, shader cycles since the workgroup's start: median [min..max]")
+for i in range(1, 8):
+    c = s[:, i]
+    print(f"  {names[i]:>22}: {c.median():8.0f} [{c.min():8.0f} .. {c.max():8.0f}]")
+print(f"  workgroup start skew: {(s[:, 0].max() - s[:, 0].min()) * 0.01:.2f} us; ideal MFMA cycles per stage: {72 * 65}")
