@@ -26,6 +26,16 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction); None if the summary is absent.  Not measured live."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")) as fh:
+            return float(json.load(fh)["notes"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -157,7 +167,7 @@ def main():
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_resident_kernel<4>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None,
+                         "traffic": profiled_traffic() if a.batch == 64 else None,
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
                          "launches_timed": launches},
         }

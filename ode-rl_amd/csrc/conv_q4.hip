@@ -171,11 +171,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bid = xcd_block_id();
-  const int ct_count = a.qout >> 3;
-  const int rh = bid & 1;
-  const int ct = (bid >> 1) % ct_count;
-  const int b = (bid >> 1) / ct_count;
+  // grid = (2 * cout/32, batch): no division, no hidden-argument load on the way to the first DMA
+  const int rh = blockIdx.x & 1;
+  const int ct = blockIdx.x >> 1;
+  const int b = blockIdx.y;
   const int r0 = rh * 8;
   const bool dma = !DBG || !(a.debug & 1), mfma = !DBG || !(a.debug & 2);
 
@@ -452,14 +451,14 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------- host
 template <typename K>
-static int launch_kernel(K kernel, const ConvArgs& a, size_t lds, hipStream_t stream, bool* attr_set) {
+static int launch_kernel(K kernel, const ConvArgs& a, size_t lds, hipStream_t stream, bool* attr_set, bool grid2d) {
   ODEHIP_REQUIRE(lds <= 160 * 1024, "conv_q4: LDS request %zu exceeds 160 KiB", lds);
   if (!*attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *attr_set = true;
   }
-  const int grid = a.batch * (a.qout / 8) * 2;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds, stream, a);
+  const dim3 grid = grid2d ? dim3((a.qout / 8) * 2, a.batch) : dim3(a.batch * (a.qout / 8) * 2);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, a);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
@@ -468,8 +467,8 @@ template <int NCHUNK>
 static int launch_resident(const ConvArgs& a, hipStream_t stream) {
   static bool attr_set = false, attr_set_dbg = false;
   const size_t lds = (size_t)NCHUNK * 30 * 1024 + 2048;
-  if (a.debug) return launch_kernel(conv3x3_resident_kernel<NCHUNK, true>, a, lds, stream, &attr_set_dbg);
-  return launch_kernel(conv3x3_resident_kernel<NCHUNK, false>, a, lds, stream, &attr_set);
+  if (a.debug) return launch_kernel(conv3x3_resident_kernel<NCHUNK, true>, a, lds, stream, &attr_set_dbg, true);
+  return launch_kernel(conv3x3_resident_kernel<NCHUNK, false>, a, lds, stream, &attr_set, true);
 }
 
 template <int KS, int MC, int NBUF>
@@ -478,7 +477,7 @@ static int launch_ring(const ConvArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   const int nchunk = a.qin / (2 * MC);
   const int nbuf_alloc = (NBUF < nchunk) ? NBUF : nchunk;
-  return launch_kernel(conv_ring_kernel<KS, MC, NBUF>, a, (size_t)nbuf_alloc * C::STAGE_BYTES + 64, stream, &attr_set);
+  return launch_kernel(conv_ring_kernel<KS, MC, NBUF>, a, (size_t)nbuf_alloc * C::STAGE_BYTES + 64, stream, &attr_set, false);
 }
 
 int g_debug_flags = 0;
