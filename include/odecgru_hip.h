@@ -105,6 +105,21 @@ int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_n
                         int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---- odeint, adaptive dopri5 (torchdiffeq Dopri5Solver; the reference's default method, configs.yaml:79) ------ */
+
+size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times);
+
+/* Same tensors as odehip_odeint_fixed.  rtol/atol as passed by DiffEqSolver (modules/DiffEqSolver.py:13: 1e-4, 1e-5).
+ * Step control runs on the device (global RMS norm over the whole batch, as torchdiffeq); outputs are the quartic
+ * dense output at t[i].  The call returns after the controller has reported completion (it polls a pinned host
+ * mailbox; it does not synchronise the stream otherwise).  stats_host[4] (may be NULL) = {nfe, n_accept, n_reject,
+ * attempts enqueued}.  first_step > 0 is torchdiffeq's options={'first_step': dt} (skips the initial-step heuristic);
+ * max_steps <= 0 means unlimited (torchdiffeq max_num_steps = 2^31-1).
+ * Errors: ODEHIP_ENOTCONV (dt underflow / max_steps), ODEHIP_ENAN (non-finite error ratio). */
+int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
+                         float rtol, float atol, double first_step, int max_steps, float* out_nchw, int* stats_host,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

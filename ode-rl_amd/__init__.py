@@ -3,7 +3,7 @@
 Public surface = the reference's: `odeint`, `DiffEqSolver`, `ODEFunc`, `create_convnet`.
 """
 from . import _lib  # noqa: F401
-from .odeint import odeint  # noqa: F401
+from .odeint import odeint, last_stats  # noqa: F401
 from .helpers.utils import create_convnet  # noqa: F401
 from .modules.DiffEqSolver import DiffEqSolver, ODEFunc  # noqa: F401
 

@@ -36,7 +36,7 @@ struct Carver {
   }
 };
 
-static int check_stack(const odehip_convstack* f) {
+int check_stack(const odehip_convstack* f) {
   ODEHIP_REQUIRE(f, "convstack: null descriptor");
   ODEHIP_REQUIRE(f->n_convs >= 1 && f->n_convs <= ODEHIP_MAX_LAYERS, "convstack: n_convs %d out of range", f->n_convs);
   ODEHIP_REQUIRE(f->ks == 3 || f->ks == 1 || f->ks == 5, "convstack: kernel size %d unsupported", f->ks);
@@ -49,7 +49,7 @@ static int check_stack(const odehip_convstack* f) {
   return ODEHIP_OK;
 }
 
-static int max_hidden(const odehip_convstack* f) {
+int max_hidden(const odehip_convstack* f) {
   int m = 32;
   for (int i = 1; i < f->n_convs; ++i) m = f->channels[i] > m ? f->channels[i] : m;
   return m;
@@ -76,8 +76,8 @@ static int upload_floats(float* dst, const float* src, int n, hipStream_t stream
 static inline size_t state_bytes(int batch, int channels) { return (size_t)batch * channels * kPix * sizeof(float); }
 
 // Enqueue f(x) with the stage-combine fused into the last conv.  ping/pong hold hidden activations.
-static int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong,
-                     const CombineArgs* cmb, float* plain_dst, hipStream_t stream) {
+int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong, const CombineArgs* cmb,
+              float* plain_dst, const int* skip, hipStream_t stream) {
   const float* cur = x_q4;
   for (int l = 0; l < f->n_convs; ++l) {
     const bool last = (l == f->n_convs - 1);
@@ -90,6 +90,7 @@ static int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, fl
     a.w_packed = f->w_packed[l];
     a.bias = f->bias[l];
     a.batch = batch;
+    a.skip = skip;
     if (!last) {
       a.relu = 1;
       a.dst = (l & 1) ? pong : ping;
@@ -173,7 +174,7 @@ extern "C" int odehip_convstack_forward(const odehip_convstack* f, const float* 
   memset(&cmb, 0, sizeof(cmb));
   cmb.k_out = out;
   cmb.k_scale = negate ? -1.0f : 1.0f;
-  rc = enqueue_f(f, x, batch, ping, pong, &cmb, nullptr, stream);
+  rc = enqueue_f(f, x, batch, ping, pong, &cmb, nullptr, nullptr, stream);
   if (rc != ODEHIP_OK) return rc;
   return odehip_q4_to_nchw(out, out_nchw, batch, f->channels[f->n_convs], stream);
 }
@@ -252,21 +253,21 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.c2[0] = 1.0f;
       c.out2 = ynew;
       c.out2_nchw = ynew_nchw;
-      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
     } else if (method == ODEHIP_MIDPOINT) {
       // x = y + h/2*k1 ; y1 = y + h*f(x)
       c.n_prev = 0;
       c.c1[0] = 0.5f;
       c.out1 = xs;
-      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       c.c1[0] = 0.0f;
       c.out1 = nullptr;
       c.c2[0] = 1.0f;
       c.out2 = ynew;
       c.out2_nchw = ynew_nchw;
-      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
     } else {
       // 3/8 rule (torchdiffeq rk4_alt_step_func)
@@ -276,7 +277,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.k_out = k[0];
       c.c1[0] = third;
       c.out1 = xs;
-      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       // stage 2: k2 = f(x2); x3 = y + h*(k2 - k1/3)
       c.n_prev = 1;
@@ -284,7 +285,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.k_out = k[1];
       c.c1[0] = -third;
       c.c1[1] = 1.0f;
-      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       // stage 3: k3 = f(x3); x4 = y + h*(k1 - k2 + k3)
       c.n_prev = 2;
@@ -293,7 +294,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.c1[0] = 1.0f;
       c.c1[1] = -1.0f;
       c.c1[2] = 1.0f;
-      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
       // stage 4: k4 = f(x4); y1 = y + h*(k1 + 3(k2+k3) + k4)/8
       c.n_prev = 3;
@@ -306,7 +307,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.c2[3] = 0.125f;
       c.out2 = ynew;
       c.out2_nchw = ynew_nchw;
-      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, stream);
+      rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, nullptr, stream);
       if (rc != ODEHIP_OK) return rc;
     }
   }

@@ -81,7 +81,7 @@ __device__ __forceinline__ f32x16 bias_init(const float* bias, int ct, int kq) {
 }
 
 // ---- epilogue: lane (pixel i32, half kq) holds channel quads 2g+kq of this 32-channel tile
-__device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, int b, int ct, int P, int kq) {
+__device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, int b, int ct, int P, int kq, int wave) {
   if (!a.combine) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -96,6 +96,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
   }
   const CombineArgs& m = a.cmb;
   const float h = m.h_ptr ? *m.h_ptr : 1.0f;
+  float esum = 0.0f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int Q = ct * 8 + 2 * g + kq;
@@ -107,10 +108,12 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
       const f32x4 yv = *(const f32x4*)(m.y + off);
       f32x4 sa = kc * m.c1[m.n_prev];
       f32x4 sb = kc * m.c2[m.n_prev];
+      f32x4 se = kc * m.ce[m.n_prev];
       for (int j = 0; j < m.n_prev; ++j) {
         const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
         sa += kp * m.c1[j];
         sb += kp * m.c2[j];
+        se += kp * m.ce[j];
       }
       if (m.out1) *(f32x4*)(m.out1 + off) = yv + sa * h;
       const f32x4 o2 = yv + sb * h;
@@ -119,7 +122,22 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
         float* o = m.out2_nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
         o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
       }
+      if (m.err_partials) {
+        const f32x4 y1 = *(const f32x4*)(m.err_y1 + off);
+        const f32x4 e = se * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float tol = m.atol + m.rtol * fmaxf(fabsf(yv[i]), fabsf(y1[i]));
+          const float r = e[i] / tol;
+          esum += r * r;
+        }
+      }
     }
+  }
+  if (m.err_partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+    if ((threadIdx.x & 63) == 0) m.err_partials[(blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave] = esum;
   }
 }
 
@@ -205,6 +223,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs
   if (dma) {
 #pragma unroll
     for (int g = 0; g < G; ++g) issue_one(0, g);
+  }
+  if (a.skip && *a.skip) {  // adaptive solver finished while this launch was queued: drain the DMAs and leave
+    wait_vmcnt<0>();
+    return;
   }
   if (DBG) st.take(1);
   // the zero page of the x halo (read by edge lanes instead of the wrapped neighbour pixel)
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs
     if (acc[0] == 12345.678f) a.dst[0] = acc[1];  // keep the accumulators live
     return;
   }
-  epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq);
+  epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq, wave);
   if (DBG) st.flush(a);
 }
 
@@ -424,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
   };
 
   // ---- K pipeline: NBUF-deep ring, counted waits, one raw barrier per chunk
+  if (a.skip && *a.skip) return;  // adaptive solver finished while this launch was queued
   const int pre = (NBUF - 1 < nchunk) ? NBUF - 1 : nchunk;
   if (dma)
     for (int c = 0; c < pre; ++c) issue(c, c);
@@ -445,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
     if (acc[0] == 12345.678f) a.dst[0] = acc[1];
     return;
   }
-  epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq);
+  epilogue(a, acc, b, ct, (r0 + wave * 2) * 16 + i32, kq, wave);
   st.flush(a);
 }
 

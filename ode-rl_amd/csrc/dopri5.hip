@@ -1,0 +1,505 @@
+// dopri5.hip -- adaptive Dormand-Prince 5(4) with a DEVICE-SIDE step controller (gfx950).
+//
+// Restates torchdiffeq 0.2.1's Dopri5Solver (_impl/rk_common.py: _adaptive_step, _runge_kutta_step,
+// _compute_error_ratio, _optimal_step_size; _impl/misc.py: _select_initial_step; _impl/interp.py) as called by the
+// reference at /root/reference/modules/DiffEqSolver.py:37,45-46 (default method, configs.yaml:79), with the same
+// decisions in the same floating-point types (float64 time, fp32 state and error ratio), but without torchdiffeq's
+// >= 3 host synchronisations per attempted step: accept/reject, the next step size, which output times fall inside
+// the accepted step and the "done" test all live in a small state block in device memory written by a one-workgroup
+// controller kernel.  The host only bounds its run-ahead by polling a pinned mailbox that the controller updates.
+//
+// One attempted step = 6 evaluations of f (30 conv launches; stage combines and the error-norm partial sums are
+// fused into the last conv of each f) + controller + finish (dense output for the output times inside the step,
+// FSAL hand-over y <- y1, k1 <- k7, and the first stage input of the next attempt).
+#include <math.h>
+#include <string.h>
+#include <time.h>
+
+#include "odehip_internal.h"
+
+namespace odehip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Dormand-Prince-Shampine tableau (torchdiffeq/_impl/dopri5.py)
+static const double kBeta[6][6] = {
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+};
+static const double kCErr[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                                -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
+static const double kCMid[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
+                                -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
+                                -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+
+struct DopriState {
+  double t0, t1, dt;   // accepted interval [t0, t1]; size of the attempt in flight
+  float h;             // (float)dt: what meets the fp32 state (torchdiffeq casts dt to y.dtype)
+  float h_used;        // step size of the attempt that was just judged (for the dense output)
+  float h0;            // initial-step heuristic scratch
+  float ratio;
+  int accept, done, status;
+  int j_next, j_lo, j_hi;
+  int n_accept, n_reject, nfe, n_steps;
+  int n_ctrl;          // controller launches (attempts enqueued by the host, real or skipped)
+  float rtol, atol;
+  int n_times, n_partials;
+  long long n_elems;
+  int max_steps;
+};
+
+struct Mailbox {  // pinned host memory, written by the controller with system-scope stores
+  volatile int steps_done, done, status, n_accept, n_reject, nfe;
+};
+
+// ---- deterministic block reduction of `n` floats (fixed order), result valid in thread 0
+__device__ float block_sum(const float* v, int n, float* sh) {
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  return sh[0];
+}
+
+// partial sums of ((a - b) / (atol + |y|*rtol))^2 per workgroup (b may be null)
+__global__ __launch_bounds__(256) void scaled_sumsq_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ y, float atol, float rtol,
+                                                           long long n4, float* __restrict__ partials) {
+  __shared__ float sh[256];
+  float s = 0.0f;
+  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 av = ((const f32x4*)a)[i], yv = ((const f32x4*)y)[i];
+    f32x4 d = av;
+    if (b) d -= ((const f32x4*)b)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float r = d[k] / (atol + fabsf(yv[k]) * rtol);
+      s += r * r;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+// out = y + h * sum_j c[j] * k[j]   (h from device memory)
+struct LinComb {
+  const float* y;
+  const float* k[ODEHIP_MAX_STAGES];
+  float c[ODEHIP_MAX_STAGES];
+  int n;
+  const float* h_ptr;
+  float* out;
+  const int* skip;
+};
+__global__ __launch_bounds__(256) void lincomb_kernel(LinComb a, long long n4) {
+  if (a.skip && *a.skip) return;
+  const float h = *a.h_ptr;
+  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 s = ((const f32x4*)a.k[0])[i] * a.c[0];
+    for (int j = 1; j < a.n; ++j) s += ((const f32x4*)a.k[j])[i] * a.c[j];
+    ((f32x4*)a.out)[i] = ((const f32x4*)a.y)[i] + s * h;
+  }
+}
+
+// _select_initial_step, first half: d0, d1 -> h0
+__global__ __launch_bounds__(256) void init1_kernel(DopriState* st, const float* p0, const float* p1, int np) {
+  __shared__ float sh[256];
+  const float s0 = block_sum(p0, np, sh);
+  __syncthreads();
+  const float s1 = block_sum(p1, np, sh);
+  if (threadIdx.x == 0) {
+    const float n = (float)st->n_elems;
+    const float d0 = sqrtf(s0 / n), d1 = sqrtf(s1 / n);
+    st->h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+    st->ratio = d1;  // parked for init2
+  }
+}
+
+// second half: d2 -> dt; arms the first attempt
+__global__ __launch_bounds__(256) void init2_kernel(DopriState* st, const float* p2, int np, const double* t_out) {
+  __shared__ float sh[256];
+  const float s2 = block_sum(p2, np, sh);
+  if (threadIdx.x == 0) {
+    const float n = (float)st->n_elems;
+    const float h0 = st->h0, d1 = st->ratio;
+    const float d2 = sqrtf(s2 / n) / h0;
+    float h1;
+    if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
+    else h1 = powf(0.01f / fmaxf(d1, d2), 1.0f / 5.0f);
+    const double dt = (double)fminf(100.0f * h0, h1);
+    st->t0 = st->t1 = t_out[0];
+    st->dt = dt;
+    st->h = (float)dt;
+    st->nfe = 2;
+    st->j_next = 1;
+    st->done = st->n_times <= 1;
+  }
+}
+
+// _adaptive_step's scalar part: error ratio, accept, output range, next dt (torchdiffeq _optimal_step_size)
+__global__ __launch_bounds__(256) void controller_kernel(DopriState* st, const float* partials, const double* t_out,
+                                                          Mailbox* mb) {
+  __shared__ float sh[256];
+  if (st->done) {  // an attempt the host enqueued after the solve finished: only acknowledge it
+    if (threadIdx.x == 0) {
+      st->accept = 0;
+      st->j_lo = st->j_hi = st->j_next;
+      st->n_ctrl += 1;
+      __hip_atomic_store((int*)&mb->steps_done, st->n_ctrl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  const float s = block_sum(partials, st->n_partials, sh);
+  if (threadIdx.x != 0) return;
+  const float ratio = sqrtf(s / (float)st->n_elems);
+  const bool finite = ratio == ratio && ratio < INFINITY;
+  const bool accept = ratio <= 1.0f;
+  st->ratio = ratio;
+  st->accept = accept;
+  st->h_used = st->h;
+  st->nfe += 6;
+  st->n_steps += 1;
+  const double dt = st->dt;
+  int status = 0;
+  if (!finite) status = ODEHIP_ENAN;  // torchdiffeq asserts isfinite(y) at the next step; a NaN ratio never accepts
+  if (accept) {
+    const double t1n = st->t1 + dt;
+    st->t0 = st->t1;
+    st->t1 = t1n;
+    st->n_accept += 1;
+    int j = st->j_next;
+    st->j_lo = j;
+    while (j < st->n_times && t_out[j] <= t1n) ++j;  // outputs inside (t0, t1]: `while next_t > t1` is false
+    st->j_hi = j;
+    st->j_next = j;
+  } else {
+    st->n_reject += 1;
+    st->j_lo = st->j_hi = st->j_next;
+  }
+  // dt_next (float64, order 5, safety 0.9, ifactor 10, dfactor 0.2 -- 1 after an accepted step)
+  double dtn;
+  if (ratio == 0.0f) {
+    dtn = dt * 10.0;
+  } else {
+    const double dfactor = ratio < 1.0f ? 1.0 : 0.2;
+    const double fac = fmin(10.0, fmax(0.9 / pow((double)ratio, 0.2), dfactor));
+    dtn = dt * fac;
+  }
+  st->dt = dtn;
+  st->h = (float)dtn;
+  const bool done = st->j_next >= st->n_times;
+  if (!done) {
+    if (!(st->t1 + dtn > st->t1)) status = ODEHIP_ENOTCONV;       // "underflow in dt"
+    if (st->n_steps >= st->max_steps) status = ODEHIP_ENOTCONV;    // max_num_steps
+  }
+  if (status) st->status = status;
+  st->done = done || status != 0;
+  mb->n_accept = st->n_accept;
+  mb->n_reject = st->n_reject;
+  mb->nfe = st->nfe;
+  mb->status = st->status;
+  mb->done = st->done;
+  st->n_ctrl += 1;
+  __hip_atomic_store((int*)&mb->steps_done, st->n_ctrl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Elementwise tail of an attempt.  On accept: dense output for the output times inside the step (quartic of
+// _interp_fit/_interp_evaluate), then y <- y1, k1 <- k7 (FSAL).  Always: x2 = y + h_next * beta21 * k1.
+struct FinishArgs {
+  const DopriState* st;
+  const double* t_out;
+  float* y;          // current state (Q4), updated on accept
+  const float* y1;   // candidate state
+  float* k[7];       // k[0] = k1 (updated on accept from k[6])
+  float* x2;         // stage-2 input of the next attempt
+  float* out_nchw;   // (T,B,C,16,16)
+  int channels;
+  long long state_floats;
+};
+__global__ __launch_bounds__(256) void finish_kernel(FinishArgs a, long long n4, float cm0, float cm2, float cm3, float cm4,
+                                                     float cm5, float cm6) {
+  const DopriState* st = a.st;
+  const int accept = st->accept, j_lo = st->j_lo, j_hi = st->j_hi;
+  if (st->done && !(accept && j_hi > j_lo)) return;  // nothing left to write
+  const float hu = st->h_used, hn = st->h;
+  const double t0 = st->t0, t1 = st->t1;
+  const bool done = st->done;
+  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    f32x4 y0 = ((const f32x4*)a.y)[i];
+    f32x4 k1 = ((const f32x4*)a.k[0])[i];
+    if (accept) {
+      const f32x4 y1 = ((const f32x4*)a.y1)[i];
+      const f32x4 k7 = ((const f32x4*)a.k[6])[i];
+      if (j_hi > j_lo) {
+        const f32x4 k3 = ((const f32x4*)a.k[2])[i], k4 = ((const f32x4*)a.k[3])[i], k5 = ((const f32x4*)a.k[4])[i],
+                    k6 = ((const f32x4*)a.k[5])[i];
+        const f32x4 ymid = y0 + (k1 * cm0 + k3 * cm2 + k4 * cm3 + k5 * cm4 + k6 * cm5 + k7 * cm6) * hu;
+        const f32x4 ca = (k7 - k1) * (2.0f * hu) - (y1 + y0) * 8.0f + ymid * 16.0f;
+        const f32x4 cb = (k1 * 5.0f - k7 * 3.0f) * hu + y0 * 18.0f + y1 * 14.0f - ymid * 32.0f;
+        const f32x4 cc = (k7 - k1 * 4.0f) * hu - y0 * 11.0f - y1 * 5.0f + ymid * 16.0f;
+        const f32x4 cd = k1 * hu;
+        // element i*4.. of the Q4 state -> NCHW: i = (b*Q + q)*256 + p
+        const long long p = i & 255, bq = i >> 8;
+        for (int j = j_lo; j < j_hi; ++j) {
+          const float x = (float)((a.t_out[j] - t0) / (t1 - t0));
+          f32x4 tot = y0 + cd * x;
+          float xp = x * x;
+          tot += cc * xp;
+          xp *= x;
+          tot += cb * xp;
+          xp *= x;
+          tot += ca * xp;
+          float* o = a.out_nchw + (size_t)j * a.state_floats + (size_t)bq * 4 * kPix + p;
+          o[0] = tot.x; o[kPix] = tot.y; o[2 * kPix] = tot.z; o[3 * kPix] = tot.w;
+        }
+      }
+      y0 = y1;
+      k1 = k7;
+      if (!done) {
+        ((f32x4*)a.y)[i] = y0;
+        ((f32x4*)a.k[0])[i] = k1;
+      }
+    }
+    if (!done) ((f32x4*)a.x2)[i] = y0 + k1 * (hn * 0.2f);  // beta21 = 1/5
+  }
+}
+
+struct DoublePack {
+  double v[32];
+};
+__global__ void fill_doubles_kernel(double* dst, DoublePack p, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+// options={'first_step': dt} of torchdiffeq: skip the heuristic (f0 is still evaluated: nfe starts at 1)
+__global__ void arm_first_step_kernel(DopriState* st, const double* t_out, double dt) {
+  st->t0 = st->t1 = t_out[0];
+  st->dt = dt;
+  st->h = (float)dt;
+  st->nfe = 1;
+  st->j_next = 1;
+  st->done = st->n_times <= 1;
+}
+__global__ void init_state_kernel(DopriState* st, float rtol, float atol, int n_times, int n_partials, long long n_elems,
+                                  int max_steps) {
+  DopriState z;
+  memset(&z, 0, sizeof(z));
+  z.rtol = rtol;
+  z.atol = atol;
+  z.n_times = n_times;
+  z.n_partials = n_partials;
+  z.n_elems = n_elems;
+  z.max_steps = max_steps;
+  *st = z;
+}
+
+static Mailbox* g_mailbox = nullptr;
+
+static double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong, const CombineArgs* cmb,
+              float* plain_dst, const int* skip, hipStream_t stream);
+int check_stack(const odehip_convstack* f);
+int max_hidden(const odehip_convstack* f);
+
+}  // namespace odehip
+
+using namespace odehip;
+
+static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+// Workspace: [state | t_out[T] | partials x3 | ping | pong | xs | y | y1 | k1..k7]
+extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times) {
+  if (!f || batch <= 0 || n_times <= 0) return 0;
+  const size_t st = al256((size_t)batch * f->channels[0] * kPix * 4);
+  const size_t hid = al256((size_t)batch * max_hidden(f) * kPix * 4);
+  const size_t np = (size_t)batch * (f->channels[0] / 32) * 2 * 4;
+  return al256(sizeof(DopriState)) + al256((size_t)n_times * 8) + 3 * al256((np > 1024 ? np : 1024) * 4) + 2 * hid + 10 * st;
+}
+
+extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
+                                    int batch, float rtol, float atol, double first_step, int max_steps, float* out_nchw,
+                                    int* stats_host, void* workspace, size_t workspace_bytes, void* stream_) {
+  int rc = check_stack(f);
+  if (rc != ODEHIP_OK) return rc;
+  ODEHIP_REQUIRE(z0_nchw && t_host && out_nchw && workspace, "odeint_dopri5: null pointer");
+  ODEHIP_REQUIRE(n_times >= 1 && batch > 0, "odeint_dopri5: bad sizes (n_times %d, batch %d)", n_times, batch);
+  ODEHIP_REQUIRE(f->channels[0] == f->channels[f->n_convs], "odeint_dopri5: f must map C -> C channels");
+  ODEHIP_REQUIRE(rtol > 0 && atol >= 0, "odeint_dopri5: rtol must be > 0 and atol >= 0");
+  for (int i = 1; i < n_times; ++i)
+    ODEHIP_REQUIRE(t_host[i] > t_host[i - 1], "odeint_dopri5: t must be strictly increasing (t[%d]=%g, t[%d]=%g)", i - 1,
+                   t_host[i - 1], i, t_host[i]);
+  ODEHIP_REQUIRE(workspace_bytes >= odehip_dopri5_workspace_bytes(f, batch, n_times), "odeint_dopri5: workspace too small");
+  if (max_steps <= 0) max_steps = 1 << 30;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int C = f->channels[0];
+  const size_t st_b = (size_t)batch * C * kPix * 4, st_f = st_b / 4;
+  const long long n4 = (long long)st_f / 4;
+  const int n_conv_partials = batch * (C / 32) * 2 * 4;
+  const int red_grid = 256;
+
+  if (!g_mailbox) {
+    // 4 KiB of pinned, coherent host memory for the controller's progress word: the only allocation this library makes
+    ODEHIP_CHECK_HIP(hipHostMalloc((void**)&g_mailbox, 4096, hipHostMallocCoherent));
+  }
+  memset((void*)g_mailbox, 0, sizeof(Mailbox));
+
+  char* base = (char*)workspace;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base + off; off += al256(bytes); return p; };
+  DopriState* state = (DopriState*)take(sizeof(DopriState));
+  double* t_dev = (double*)take((size_t)n_times * 8);
+  const size_t pbytes = (size_t)(n_conv_partials > 1024 ? n_conv_partials : 1024) * 4;
+  float* part0 = (float*)take(pbytes);
+  float* part1 = (float*)take(pbytes);
+  float* part2 = (float*)take(pbytes);
+  float* ping = (float*)take((size_t)batch * max_hidden(f) * kPix * 4);
+  float* pong = (float*)take((size_t)batch * max_hidden(f) * kPix * 4);
+  float* xs = (float*)take(st_b);
+  float* y = (float*)take(st_b);
+  float* y1 = (float*)take(st_b);
+  float* k[7];
+  for (int i = 0; i < 7; ++i) k[i] = (float*)take(st_b);
+  const int* skip = &state->done;
+
+  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, state, rtol, atol, n_times, n_conv_partials,
+                     (long long)st_f, max_steps);
+  for (int o = 0; o < n_times; o += 32) {
+    DoublePack p;
+    const int m = n_times - o < 32 ? n_times - o : 32;
+    for (int i = 0; i < m; ++i) p.v[i] = t_host[o + i];
+    hipLaunchKernelGGL(fill_doubles_kernel, dim3(1), dim3(32), 0, stream, t_dev + o, p, m);
+  }
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  ODEHIP_CHECK_HIP(hipMemcpyAsync(out_nchw, z0_nchw, st_b, hipMemcpyDeviceToDevice, stream));  // solution[0] = y0
+  rc = odehip_nchw_to_q4(z0_nchw, y, batch, C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  if (n_times == 1) {
+    if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
+    return ODEHIP_OK;
+  }
+
+  // ---- _select_initial_step: f0, d0, d1 -> h0; f(y0 + h0 f0); d2 -> dt
+  CombineArgs c;
+  memset(&c, 0, sizeof(c));
+  c.k_scale = 1.0f;
+  c.k_out = k[0];
+  rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
+  if (rc != ODEHIP_OK) return rc;
+  LinComb lc;
+  memset(&lc, 0, sizeof(lc));
+  lc.y = y;
+  lc.k[0] = k[0];
+  lc.n = 1;
+  lc.out = xs;
+  if (first_step > 0.0) {
+    hipLaunchKernelGGL(arm_first_step_kernel, dim3(1), dim3(1), 0, stream, state, t_dev, first_step);
+  } else {
+    hipLaunchKernelGGL(scaled_sumsq_kernel, dim3(red_grid), dim3(256), 0, stream, y, (const float*)nullptr, y, atol, rtol, n4, part0);
+    hipLaunchKernelGGL(scaled_sumsq_kernel, dim3(red_grid), dim3(256), 0, stream, k[0], (const float*)nullptr, y, atol, rtol, n4, part1);
+    hipLaunchKernelGGL(init1_kernel, dim3(1), dim3(256), 0, stream, state, part0, part1, red_grid);
+    lc.c[0] = 1.0f;
+    lc.h_ptr = &state->h0;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(1024), dim3(256), 0, stream, lc, n4);
+    c.k_out = k[1];
+    rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, nullptr, stream);
+    if (rc != ODEHIP_OK) return rc;
+    hipLaunchKernelGGL(scaled_sumsq_kernel, dim3(red_grid), dim3(256), 0, stream, k[1], k[0], y, atol, rtol, n4, part2);
+    hipLaunchKernelGGL(init2_kernel, dim3(1), dim3(256), 0, stream, state, part2, red_grid, t_dev);
+  }
+  lc.c[0] = (float)kBeta[0][0];
+  lc.h_ptr = &state->h;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(1024), dim3(256), 0, stream, lc, n4);  // x2 of the first attempt
+  ODEHIP_CHECK_HIP(hipGetLastError());
+
+  FinishArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.st = state;
+  fa.t_out = t_dev;
+  fa.y = y;
+  fa.y1 = y1;
+  for (int i = 0; i < 7; ++i) fa.k[i] = k[i];
+  fa.x2 = xs;
+  fa.out_nchw = out_nchw;
+  fa.channels = C;
+  fa.state_floats = (long long)st_f;
+
+  // ---- attempted steps; the host runs at most RUN_AHEAD attempts ahead of the device
+  const int RUN_AHEAD = 2;
+  const double t_start = now_s();
+  int enq = 0;
+  for (;;) {
+    for (int s = 2; s <= 7; ++s) {  // k_s = f(x_s); fused: x_{s+1} = y + h*sum beta_{s+1,j} k_j   (s = 7: error norm)
+      memset(&c, 0, sizeof(c));
+      c.k_scale = 1.0f;
+      c.y = y;
+      c.h_ptr = &state->h;
+      c.n_prev = s - 1;
+      for (int j = 0; j < s - 1; ++j) c.k_prev[j] = k[j];
+      c.k_out = k[s - 1];
+      if (s <= 6) {
+        for (int j = 0; j < s; ++j) c.c1[j] = (float)kBeta[s - 1][j];
+        c.out1 = s < 6 ? xs : y1;  // x7 = y1 (c_sol equals the last beta row)
+      } else {
+        for (int j = 0; j < 7; ++j) c.ce[j] = (float)kCErr[j];
+        c.err_y1 = y1;
+        c.err_partials = part0;
+        c.rtol = rtol;
+        c.atol = atol;
+      }
+      rc = enqueue_f(f, s < 7 ? xs : y1, batch, ping, pong, &c, nullptr, skip, stream);
+      if (rc != ODEHIP_OK) return rc;
+    }
+    hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, part0, t_dev, g_mailbox);
+    hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, stream, fa, n4, (float)kCMid[0], (float)kCMid[2],
+                       (float)kCMid[3], (float)kCMid[4], (float)kCMid[5], (float)kCMid[6]);
+    ODEHIP_CHECK_HIP(hipGetLastError());
+    ++enq;
+    // bound the run-ahead; leave as soon as the controller reports done
+    while (!g_mailbox->done && g_mailbox->steps_done + RUN_AHEAD < enq) {
+      if (now_s() - t_start > 120.0) {
+        set_error("odeint_dopri5: no progress from the device for 120 s (steps done %d of %d enqueued)", g_mailbox->steps_done, enq);
+        return ODEHIP_EHIP;
+      }
+    }
+    if (g_mailbox->done) break;
+  }
+  // attempts enqueued after `done` do nothing (skip flag); wait for the last controller so the mailbox is final
+  while (g_mailbox->steps_done < enq) {
+    if (now_s() - t_start > 120.0) {
+      set_error("odeint_dopri5: device did not drain");
+      return ODEHIP_EHIP;
+    }
+  }
+  if (stats_host) {
+    stats_host[0] = g_mailbox->nfe;
+    stats_host[1] = g_mailbox->n_accept;
+    stats_host[2] = g_mailbox->n_reject;
+    stats_host[3] = enq;
+  }
+  if (g_mailbox->status == ODEHIP_ENAN) {
+    set_error("odeint_dopri5: non-finite error ratio (non-finite values in state `y`)");
+    return ODEHIP_ENAN;
+  }
+  if (g_mailbox->status == ODEHIP_ENOTCONV) {
+    set_error("odeint_dopri5: underflow in dt or max_num_steps exceeded");
+    return ODEHIP_ENOTCONV;
+  }
+  return ODEHIP_OK;
+}

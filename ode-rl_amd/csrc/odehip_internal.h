@@ -47,6 +47,13 @@ struct CombineArgs {
   float c1[ODEHIP_MAX_STAGES + 1];
   float c2[ODEHIP_MAX_STAGES + 1];
   float k_scale;  // k_cur is multiplied by this first (-1 for backwards=True / reversed time)
+  // adaptive error norm (dopri5, last stage): err = h * (sum_j ce[j]*k_prev[j] + ce[n_prev]*k_cur),
+  // tol = atol + rtol*max(|y|, |err_y1|); every wave writes sum((err/tol)^2) of its 32x32 tile to
+  // err_partials[4*workgroup + wave] (no atomics: the controller adds them in a fixed order)
+  const float* err_y1;
+  float* err_partials;
+  float ce[ODEHIP_MAX_STAGES + 1];
+  float rtol, atol;
 };
 
 struct ConvArgs {
@@ -62,6 +69,7 @@ struct ConvArgs {
   int relu;
   int combine; // 0: plain store (+relu); 1: CombineArgs epilogue
   int debug;   // diagnostic ablation bits (tools/conv_microbench.py): 1 skip DMA, 2 skip MFMA, 4 skip epilogue
+  const int* skip;          // if non-null and *skip != 0 the kernel does nothing (adaptive solver already done)
   unsigned long long* dbg;  // debug & 8: per-workgroup stamps (8 x u64 per workgroup)
   CombineArgs cmb;
 };

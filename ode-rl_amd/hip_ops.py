@@ -168,3 +168,24 @@ def odeint_fixed(stack, method, z0, t):
     _lib.check(lib.odehip_odeint_fixed(ctypes.byref(desc), m, _ptr(z0), tarr, n, b, _ptr(out), 0, _ptr(ws), ws.numel(),
                                        _stream()))
     return out
+
+
+def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
+    """Adaptive dopri5 trajectory; returns ((T,B,C,16,16), stats dict)."""
+    require_device_tensor(z0, "y0")
+    desc = stack.refresh()
+    z0 = z0.contiguous()
+    b, c = z0.shape[0], z0.shape[1]
+    if z0.dim() != 4 or tuple(z0.shape[2:]) != (16, 16) or c != desc.channels[0]:
+        raise ValueError(f"y0 must be (B,{desc.channels[0]},16,16) (got {tuple(z0.shape)})")
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n = len(t64)
+    lib = _lib.load()
+    nbytes = lib.odehip_dopri5_workspace_bytes(ctypes.byref(desc), b, n)
+    ws = workspace(("dopri5", b, n, tuple(desc.channels)), nbytes, z0.device)
+    out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
+    tarr = (ctypes.c_double * n)(*t64)
+    stats = (ctypes.c_int * 4)()
+    _lib.check(lib.odehip_odeint_dopri5(ctypes.byref(desc), _ptr(z0), tarr, n, b, float(rtol), float(atol), float(first_step or 0.0), int(max_steps),
+                                        _ptr(out), stats, _ptr(ws), ws.numel(), _stream()))
+    return out, {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3]}

@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import hip_ops
 
 FIXED_GRID = ("euler", "midpoint", "rk4")
+last_stats = {}  # nfe / n_accept / n_reject of the most recent dopri5 call (instrumentation)
 _t_cache = {}
 
 
@@ -85,10 +86,10 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in func.parameters())):
         from .autograd import odeint_with_grad
         return odeint_with_grad(func, y0, t, rtol, atol, method)
-    return odeint_forward(func, y0, t, rtol, atol, method)
+    return odeint_forward(func, y0, t, rtol, atol, method, options)
 
 
-def odeint_forward(func, y0, t, rtol, atol, method, negate=None):
+def odeint_forward(func, y0, t, rtol, atol, method, options=None):
     th = _host_times(t)
     _check_monotone(th)
     backwards = bool(getattr(func, "_hip_backwards", False))
@@ -100,4 +101,12 @@ def odeint_forward(func, y0, t, rtol, atol, method, negate=None):
     stack = conv_stack_of(func)
     if method in FIXED_GRID:
         return hip_ops.odeint_fixed(stack, method, y0, th)
-    raise NotImplementedError("odeint(HIP): dopri5 is not implemented yet")
+    options = options or {}
+    unknown = set(options) - {"first_step", "max_num_steps"}
+    if unknown:
+        raise ValueError(f"odeint(HIP): unsupported dopri5 options {sorted(unknown)}")
+    out, stats = hip_ops.odeint_dopri5(stack, y0, th, rtol, atol, first_step=float(options.get("first_step") or 0.0),
+                                       max_steps=int(options.get("max_num_steps") or 0))
+    last_stats.clear()
+    last_stats.update(stats)
+    return out

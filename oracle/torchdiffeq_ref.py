@@ -210,20 +210,26 @@ def _interp_evaluate(coeffs, t0, t1, t):
     return total
 
 
-def _integrate_dopri5(func, y0, t, rtol, atol, stats, norm):
+def _integrate_dopri5(func, y0, t, rtol, atol, stats, norm, options=None):
     solution = torch.empty(len(t), *y0.shape, dtype=y0.dtype)
     solution[0] = y0
     t = t.to(torch.float64)
     f0 = func(t[0].to(y0.dtype), y0)
-    dt = _select_initial_step(func, t[0], y0, ORDER - 1, rtol, atol, f0, norm)
-    stats["nfe"] = stats.get("nfe", 0) + 2
+    options = options or {}
+    max_num_steps = options.get("max_num_steps", MAX_NUM_STEPS)
+    if options.get("first_step") is None:
+        dt = _select_initial_step(func, t[0], y0, ORDER - 1, rtol, atol, f0, norm)
+        stats["nfe"] = stats.get("nfe", 0) + 2
+    else:  # torchdiffeq options={'first_step': dt}: the heuristic (and its extra f-eval) is skipped
+        dt = torch.as_tensor(options["first_step"], dtype=torch.float64)
+        stats["nfe"] = stats.get("nfe", 0) + 1
     y, f, t0, t1 = y0, f0, t[0], t[0]
     interp = [y0] * 5
     n_steps = 0
     for i in range(1, len(t)):
         next_t = t[i]
         while next_t > t1:
-            assert n_steps < MAX_NUM_STEPS, "max_num_steps exceeded"
+            assert n_steps < max_num_steps, "max_num_steps exceeded ({}>={})".format(n_steps, max_num_steps)
             ta = t1
             tb = ta + dt
             assert tb > ta, "underflow in dt {}".format(dt.item())
@@ -277,7 +283,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, stats=N
         stats["nfe"] = stats.get("nfe", 0) + per_step * (len(t) - 1)
         return _integrate_fixed(func, y0, t, method, stats)
     if method == "dopri5":
-        return _integrate_dopri5(func, y0, t, rtol, atol, stats, norm or rms_norm)
+        return _integrate_dopri5(func, y0, t, rtol, atol, stats, norm or rms_norm, options)
     raise ValueError('Invalid method "{}".'.format(method))
 
 
