@@ -105,6 +105,42 @@ int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_n
                         int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---- ConvGRU cell and the ODE-ConvGRU encoder (modules/ConvGRUCell.py:55-86, modules/ODEConvGRUCell.py:32-78) ---- */
+
+typedef struct odehip_convgru_cell {
+  int input, hidden, ks;       /* ConvGRUCell(input_dim, hidden_dim, kernel_size); GroupNorm groups of 32 channels        */
+  const float* w_gates;        /* packed conv_gates.0.weight (2*hidden, input+hidden, ks, ks)                              */
+  const float* b_gates;        /* conv_gates.0.bias                                                                        */
+  const float* gn_gates_w;     /* conv_gates.1.weight (GroupNorm gamma, 2*hidden)                                           */
+  const float* gn_gates_b;     /* conv_gates.1.bias                                                                        */
+  const float* w_can;          /* packed conv_can.0.weight (hidden, input+hidden, ks, ks)                                   */
+  const float* b_can;
+  const float* gn_can_w;
+  const float* gn_can_b;
+} odehip_convgru_cell;
+
+size_t odehip_convgru_cell_workspace_bytes(const odehip_convgru_cell* c, int batch);
+/* one step: x (B,input,16,16), h (B,hidden,16,16) -> h_next, all NCHW          (ConvGRUCell.forward, seq_len = 1) */
+int odehip_convgru_cell_forward(const odehip_convgru_cell* c, const float* x_nchw, const float* h_nchw, float* h_next_nchw,
+                                int batch, void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct odehip_encoder {
+  odehip_convstack f_enc;      /* ode_encoder_func.gradient_net                                                            */
+  odehip_convgru_cell cell;    /* cgru_cell                                                                                */
+  int head_hidden, out_ch;     /* transform_z0: Conv1x1(ch, head_hidden) -> ReLU -> Conv1x1(head_hidden, 2*out_ch)          */
+  const float* w_head0;        /* packed 1x1 weights / biases                                                              */
+  const float* b_head0;
+  const float* w_head1;
+  const float* b_head1;
+} odehip_encoder;
+
+size_t odehip_encoder_workspace_bytes(const odehip_encoder* e, int n_frames, int batch);
+/* inputs (T,B,C,16,16) time-first NCHW, t_host[T] float64 -> mean_z0, std_z0 (B,out_ch,16,16); latent (B,T,C,16,16) or NULL.
+ * ODEConvGRUCell.forward / run_ode_conv_gru(run_backwards=True); `mask` is ignored as in the reference (ConvGRUCell.py:55-86). */
+int odehip_odeconvgru_encode(const odehip_encoder* e, const float* inputs_nchw, const double* t_host, int n_frames, int batch,
+                             float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ---- odeint, adaptive dopri5 (torchdiffeq Dopri5Solver; the reference's default method, configs.yaml:79) ------ */
 
 size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times);

@@ -38,6 +38,19 @@ class ConvStack(ctypes.Structure):
     ]
 
 
+class ConvGRUCellDesc(ctypes.Structure):
+    _fields_ = [("input", ctypes.c_int), ("hidden", ctypes.c_int), ("ks", ctypes.c_int),
+                ("w_gates", ctypes.c_void_p), ("b_gates", ctypes.c_void_p), ("gn_gates_w", ctypes.c_void_p),
+                ("gn_gates_b", ctypes.c_void_p), ("w_can", ctypes.c_void_p), ("b_can", ctypes.c_void_p),
+                ("gn_can_w", ctypes.c_void_p), ("gn_can_b", ctypes.c_void_p)]
+
+
+class EncoderDesc(ctypes.Structure):
+    _fields_ = [("f_enc", ConvStack), ("cell", ConvGRUCellDesc), ("head_hidden", ctypes.c_int), ("out_ch", ctypes.c_int),
+                ("w_head0", ctypes.c_void_p), ("b_head0", ctypes.c_void_p), ("w_head1", ctypes.c_void_p),
+                ("b_head1", ctypes.c_void_p)]
+
+
 class OdeHipError(RuntimeError):
     pass
 
@@ -67,6 +80,15 @@ SIGNATURES = {
                                            ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                            ctypes.c_void_p]),
+    "odehip_convgru_cell_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvGRUCellDesc), ctypes.c_int]),
+    "odehip_convgru_cell_forward": (ctypes.c_int, [ctypes.POINTER(ConvGRUCellDesc), ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                                   ctypes.c_void_p]),
+    "odehip_encoder_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(EncoderDesc), ctypes.c_int, ctypes.c_int]),
+    "odehip_odeconvgru_encode": (ctypes.c_int, [ctypes.POINTER(EncoderDesc), ctypes.c_void_p,
+                                                ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_dopri5_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_int]),
     "odehip_odeint_dopri5": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_double, ctypes.c_int,

@@ -189,3 +189,106 @@ def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
     _lib.check(lib.odehip_odeint_dopri5(ctypes.byref(desc), _ptr(z0), tarr, n, b, float(rtol), float(atol), float(first_step or 0.0), int(max_steps),
                                         _ptr(out), stats, _ptr(ws), ws.numel(), _stream()))
     return out, {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3]}
+
+
+class PackedCell:
+    """Packed parameters of a ConvGRUCell (conv_gates / conv_can Sequentials), refreshed on parameter change."""
+
+    def __init__(self, cell):
+        self.cell = cell
+        self._stamp = None
+        self._keep = None
+        self.desc = None
+
+    def _params(self):
+        c = self.cell
+        return [c.conv_gates[0].weight, c.conv_gates[0].bias, c.conv_gates[1].weight, c.conv_gates[1].bias,
+                c.conv_can[0].weight, c.conv_can[0].bias, c.conv_can[1].weight, c.conv_can[1].bias]
+
+    def refresh(self):
+        ps = self._params()
+        stamp = tuple((p.data_ptr(), p._version) for p in ps)
+        if stamp == self._stamp:
+            return self.desc
+        for p in ps:
+            require_device_tensor(p, "ConvGRUCell parameter")
+        c = self.cell
+        ks = c.conv_gates[0].kernel_size[0]
+        if c.conv_gates[0].padding != (ks // 2, ks // 2):
+            raise ValueError("the HIP ConvGRU supports 'same' padding only")
+        if c.conv_gates[1].num_groups * 32 != 2 * c.hidden_dim or c.conv_can[1].num_groups * 32 != c.hidden_dim:
+            raise ValueError("the HIP ConvGRU needs GroupNorm groups of 32 channels (hidden_dim multiple of 32)")
+        keep = [pack_conv_weight(ps[0]), ps[1].detach().contiguous(), ps[2].detach().contiguous(), ps[3].detach().contiguous(),
+                pack_conv_weight(ps[4]), ps[5].detach().contiguous(), ps[6].detach().contiguous(), ps[7].detach().contiguous()]
+        d = _lib.ConvGRUCellDesc(input=c.input_channels, hidden=c.hidden_dim, ks=ks,
+                                 w_gates=keep[0].data_ptr(), b_gates=keep[1].data_ptr(), gn_gates_w=keep[2].data_ptr(),
+                                 gn_gates_b=keep[3].data_ptr(), w_can=keep[4].data_ptr(), b_can=keep[5].data_ptr(),
+                                 gn_can_w=keep[6].data_ptr(), gn_can_b=keep[7].data_ptr())
+        self._keep, self.desc, self._stamp = keep, d, stamp
+        return d
+
+
+def convgru_cell_forward(packed_cell, x, h):
+    require_device_tensor(x, "input_tensor")
+    require_device_tensor(h, "h_cur")
+    d = packed_cell.refresh()
+    x, h = x.contiguous(), h.contiguous()
+    b = x.shape[0]
+    if tuple(x.shape) != (b, d.input, 16, 16) or tuple(h.shape) != (b, d.hidden, 16, 16):
+        raise ValueError(f"ConvGRU step needs x (B,{d.input},16,16) and h (B,{d.hidden},16,16); got {tuple(x.shape)}, {tuple(h.shape)}")
+    lib = _lib.load()
+    nbytes = lib.odehip_convgru_cell_workspace_bytes(ctypes.byref(d), b)
+    ws = workspace(("cgru", b, d.input, d.hidden), nbytes, x.device)
+    out = torch.empty_like(h)
+    _lib.check(lib.odehip_convgru_cell_forward(ctypes.byref(d), _ptr(x), _ptr(h), _ptr(out), b, _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+class PackedEncoder:
+    """Everything `ODEConvGRUCell.forward` needs on the device: encoder dynamics, cell, 1x1 head."""
+
+    def __init__(self, f_stack, packed_cell, head):
+        self.f_stack, self.packed_cell, self.head = f_stack, packed_cell, head
+        self._stamp = None
+        self._keep = None
+        self.desc = None
+
+    def refresh(self):
+        fd = self.f_stack.refresh()
+        cd = self.packed_cell.refresh()
+        h0, h1 = self.head[0], self.head[2]
+        ps = [h0.weight, h0.bias, h1.weight, h1.bias]
+        stamp = (id(fd), id(cd)) + tuple((p.data_ptr(), p._version) for p in ps)
+        if stamp == self._stamp:
+            return self.desc
+        keep = [pack_conv_weight(h0.weight), h0.bias.detach().contiguous(), pack_conv_weight(h1.weight),
+                h1.bias.detach().contiguous()]
+        d = _lib.EncoderDesc()
+        d.f_enc = fd
+        d.cell = cd
+        d.head_hidden = h0.out_channels
+        d.out_ch = h1.out_channels // 2
+        d.w_head0, d.b_head0, d.w_head1, d.b_head1 = (k.data_ptr() for k in keep)
+        self._keep, self.desc, self._stamp = keep, d, stamp
+        return d
+
+
+def odeconvgru_encode(enc, inputs, timesteps, want_latent=False):
+    require_device_tensor(inputs, "inputs")
+    d = enc.refresh()
+    inputs = inputs.contiguous()
+    t, b, c = inputs.shape[0], inputs.shape[1], inputs.shape[2]
+    if inputs.dim() != 5 or tuple(inputs.shape[3:]) != (16, 16) or c != d.cell.hidden:
+        raise ValueError(f"inputs must be (T,B,{d.cell.hidden},16,16) time-first (got {tuple(inputs.shape)})")
+    t64 = [float(v) for v in timesteps.detach().to("cpu", torch.float64).tolist()]
+    assert t == len(t64), "Sequence length should be same as time_steps"
+    lib = _lib.load()
+    nbytes = lib.odehip_encoder_workspace_bytes(ctypes.byref(d), t, b)
+    ws = workspace(("enc", t, b, c), nbytes, inputs.device)
+    mean = torch.empty((b, d.out_ch, 16, 16), dtype=torch.float32, device=inputs.device)
+    std = torch.empty_like(mean)
+    latent = torch.empty((b, t, c, 16, 16), dtype=torch.float32, device=inputs.device) if want_latent else None
+    tarr = (ctypes.c_double * t)(*t64)
+    _lib.check(lib.odehip_odeconvgru_encode(ctypes.byref(d), _ptr(inputs), tarr, t, b, _ptr(mean), _ptr(std), _ptr(latent),
+                                            _ptr(ws), ws.numel(), _stream()))
+    return mean, std, latent

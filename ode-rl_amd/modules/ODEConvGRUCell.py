@@ -1,0 +1,42 @@
+"""Drop-in for the reference's `modules/ODEConvGRUCell.py:9-78`: same constructor and attribute names (`ode_func`,
+`cgru_cell`, `transform_z0`, `z0_dim`), whole reverse-time Euler + ConvGRU loop in ONE C-ABI call."""
+import torch
+import torch.nn as nn
+
+from .. import hip_ops
+from ..odeint import conv_stack_of
+from .ConvGRUCell import ConvGRUCell
+
+
+class ODEConvGRUCell(nn.Module):
+    def __init__(self, ode_func, opt, resolution, ch, out_ch=None, device=None, kernel_size=5):
+        super().__init__()
+        self.ode_func = ode_func
+        self.device = device
+        self.z0_diffeq_solver = None
+        if out_ch is None:
+            out_ch = ch
+        self.cgru_cell = ConvGRUCell(input_size=resolution, input_dim=ch, hidden_dim=ch, kernel_size=kernel_size,
+                                     bias=True).to(device)
+        self.z0_dim = out_ch
+        self.transform_z0 = nn.Sequential(nn.Conv2d(ch, ch, 1, 1, 0), nn.ReLU(), nn.Conv2d(ch, out_ch * 2, 1, 1, 0)).to(device)
+
+    def _packed(self):
+        p = getattr(self, "_hip_enc", None)
+        if p is None:
+            p = hip_ops.PackedEncoder(conv_stack_of(self.ode_func), self.cgru_cell._packed(), self.transform_z0)
+            object.__setattr__(self, "_hip_enc", p)
+        return p
+
+    def forward(self, inputs, timesteps, mask=None):
+        """inputs (T,B,C,H,W) time-first -> (mean_z0, std_z0), each (B, z0_dim, H, W); std is |.| (reference :32-37)."""
+        mean, std, _ = hip_ops.odeconvgru_encode(self._packed(), inputs, timesteps)
+        return mean, std
+
+    def run_ode_conv_gru(self, inputs, timesteps, run_backwards=True, mask=None):
+        """Returns (last yi, latent_ys (B,T,C,H,W)) as the reference (:39-78).  Only run_backwards=True exists on the
+        device path (it is the only mode the reference ever uses, :33)."""
+        if not run_backwards:
+            raise NotImplementedError("run_ode_conv_gru(run_backwards=False) is not supported by the HIP path")
+        _, _, latent = hip_ops.odeconvgru_encode(self._packed(), inputs, timesteps, want_latent=True)
+        return latent[:, -1], latent
