@@ -105,6 +105,15 @@ int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_n
                         int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Backward of odehip_odeint_fixed(save_for_backward = 1), on the SAME workspace (untouched in between).
+ * This is what `loss.backward()` (train_test.py:204) computes through torchdiffeq's fixed-grid ops: the exact gradient
+ * of the discrete solver.  f_dgrad->w_packed[l] = odehip_pack_conv_weight(W_l, transpose_flip = 1) in forward layer
+ * order (its bias pointers are ignored).  grad_out (T,B,C,16,16) -> grad_z0 (B,C,16,16), grad_w[l] (OIHW), grad_b[l].
+ * Deterministic (no float atomics).  Currently 64-channel 3x3 dynamics only. */
+int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method, const double* t_host,
+                                 int n_times, int batch, const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
+                                 float* const* grad_b, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- ConvGRU cell and the ODE-ConvGRU encoder (modules/ConvGRUCell.py:55-86, modules/ODEConvGRUCell.py:32-78) ---- */
 
 typedef struct odehip_convgru_cell {

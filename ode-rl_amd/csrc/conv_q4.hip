@@ -94,6 +94,39 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
     }
     return;
   }
+  if (a.combine >= 2) {
+    const BwdArgs& w = a.bwd;
+    const float hb = w.h_ptr ? *w.h_ptr : 0.0f;
+    if (a.combine == 2) {
+      const float sc = w.sc_c + w.sc_h * hb;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        v *= sc;
+        if (w.mask_src) {
+          const f32x4 mk = *(const f32x4*)(w.mask_src + off);
+          v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f;
+          v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+        }
+        *(f32x4*)(a.dst + off) = v;
+      }
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
+      const f32x4 gx = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      for (int t = 0; t < w.n_targets; ++t) {
+        const BwdTarget& T = w.tgt[t];
+        f32x4 o = gx * (T.g_c + T.g_h * hb);
+        if (T.srcA) o += *(const f32x4*)(T.srcA + off) * (T.a_c + T.a_h * hb);
+        if (T.srcB) o += *(const f32x4*)(T.srcB + off) * (T.b_c + T.b_h * hb);
+        *(f32x4*)(T.out + off) = o;
+      }
+    }
+    return;
+  }
   const CombineArgs& m = a.cmb;
   const float h = m.h_ptr ? *m.h_ptr : 1.0f;
   float esum = 0.0f;

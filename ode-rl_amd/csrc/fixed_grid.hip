@@ -1,0 +1,382 @@
+// fixed_grid.hip -- euler / midpoint / rk4(3/8) trajectories (torchdiffeq FixedGridODESolver, one step per output
+// interval; call sites /root/reference/modules/DiffEqSolver.py:37,45-46) and their BACKWARD pass.
+//
+// Backward = what the reference gets from `loss.backward()` (train_test.py:204): reverse-mode differentiation
+// through every op of the discrete solver ("discretise-then-optimise"; the reference imports `odeint`, not
+// `odeint_adjoint`: modules/DiffEqSolver.py:9).  Here it is an explicit reverse sweep:
+//   * the forward pass (save_for_backward) keeps every layer input A[n][s][l] of every evaluation of f in the
+//     workspace (HBM is 288 GB; B=64,T=10 needs 0.7 GB) -- nothing is recomputed;
+//   * per evaluation, the input-gradient chain is the SAME MFMA conv kernel run on transposed+flipped weights
+//     (odehip_pack_conv_weight(transpose_flip=1)) with the ReLU mask fused in the epilogue, and the reverse
+//     Runge-Kutta bookkeeping (gy += gx, gk_j += c h gx, seed of the next interval) fused into the epilogue of
+//     the chain's last conv -- no standalone elementwise kernels;
+//   * all weight gradients are ONE launch per layer over all evaluations (wgrad.hip).
+#include <string.h>
+
+#include "odehip_internal.h"
+
+namespace odehip {
+
+struct WgradPair {
+  const float* g;
+  const float* a;
+};
+int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
+                   hipStream_t stream);
+int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
+                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
+int check_stack(const odehip_convstack* f);
+int max_hidden(const odehip_convstack* f);
+int upload_floats(float* dst, const float* src, int n, hipStream_t stream);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+static int n_stages(int method) { return method == ODEHIP_RK4 ? 4 : (method == ODEHIP_MIDPOINT ? 2 : 1); }
+constexpr int kEsplit = 4;
+
+// Everything lives in the caller's workspace; this is the one place that knows where.
+struct FixedLayout {
+  int T, B, C, S, NH, save;  // NH = hidden activations per evaluation of f (n_convs - 1)
+  size_t st;                 // bytes of one (B,C,16,16) tensor
+  size_t hid;                // bytes of one hidden activation (B,max_hidden,16,16)
+  size_t off_h, off_ping, off_pong, off_xs, off_k, off_y, off_xin, off_hid, off_gp, off_go, off_gy, off_g2, off_tab, off_slab, total;
+  FixedLayout(const odehip_convstack* f, int batch, int n_times, int method, int save_) {
+    T = n_times; B = batch; C = f->channels[0]; S = n_stages(method); NH = f->n_convs - 1; save = save_;
+    st = al256((size_t)B * C * kPix * 4);
+    hid = al256((size_t)B * max_hidden(f) * kPix * 4);
+    size_t o = 0;
+    auto take = [&](size_t b) { size_t r = o; o += al256(b); return r; };
+    off_h = take((size_t)T * 4);
+    off_ping = take(hid);
+    off_pong = take(hid);
+    off_xs = take(st);
+    off_k = take(3 * st);
+    off_y = take((size_t)T * st);
+    off_xin = off_hid = off_gp = off_go = off_gy = off_g2 = off_tab = off_slab = 0;
+    if (save) {
+      const size_t ne = (size_t)(T - 1) * S;
+      off_xin = take(ne * st);             // stage inputs (slot s = 0 unused: it is y[n])
+      off_hid = take(ne * NH * hid);       // ReLU outputs of every evaluation
+      off_gp = take(ne * (NH + 1) * hid);  // gradients w.r.t. every conv output (filled by the backward sweep)
+      off_go = take((size_t)T * st);       // grad_out in Q4
+      off_gy = take(st);
+      off_g2 = take(2 * st);
+      off_tab = take(ne * sizeof(WgradPair));
+      off_slab = take((size_t)B * kEsplit * (64 * 64 * 9 + 64) * 4);
+    }
+    total = o;
+  }
+  float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }
+  float* y(void* ws, int n) const { return p(ws, off_y + (size_t)n * st); }
+  float* xin(void* ws, int n, int s) const { return s == 0 ? y(ws, n) : p(ws, off_xin + ((size_t)n * S + s) * st); }
+  float* hidden(void* ws, int n, int s, int l) const { return p(ws, off_hid + (((size_t)n * S + s) * NH + l) * hid); }
+  float* gp(void* ws, int n, int s, int l) const { return p(ws, off_gp + (((size_t)n * S + s) * (NH + 1) + l) * hid); }
+  float* go(void* ws, int j) const { return p(ws, off_go + (size_t)j * st); }
+};
+
+// out = (c_c + c_h*h) * in
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ out, const float* __restrict__ in, float c_c, float c_h,
+                                                    const float* h_ptr, long long n4) {
+  const float c = c_c + c_h * (h_ptr ? *h_ptr : 0.0f);
+  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+    ((f32x4*)out)[i] = ((const f32x4*)in)[i] * c;
+}
+
+struct PtrPack {
+  unsigned long long v[32];
+};
+__global__ void fill_u64_kernel(unsigned long long* dst, PtrPack p, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+static int check_common(const odehip_convstack* f, int method, const double* t_host, int n_times, int batch, const char* who) {
+  int rc = check_stack(f);
+  if (rc != ODEHIP_OK) return rc;
+  ODEHIP_REQUIRE(method == ODEHIP_EULER || method == ODEHIP_MIDPOINT || method == ODEHIP_RK4,
+                 "%s: method %d is not a fixed-grid method", who, method);
+  ODEHIP_REQUIRE(t_host, "%s: null t", who);
+  ODEHIP_REQUIRE(n_times >= 1 && n_times <= 4096 && batch > 0, "%s: bad sizes (n_times %d, batch %d)", who, n_times, batch);
+  ODEHIP_REQUIRE(f->channels[0] == f->channels[f->n_convs], "%s: f must map C -> C channels (%d -> %d)", who, f->channels[0],
+                 f->channels[f->n_convs]);
+  for (int i = 1; i < n_times; ++i)
+    ODEHIP_REQUIRE(t_host[i] > t_host[i - 1], "%s: t must be strictly increasing (t[%d]=%g, t[%d]=%g)", who, i - 1, t_host[i - 1],
+                   i, t_host[i]);
+  return ODEHIP_OK;
+}
+
+}  // namespace odehip
+
+using namespace odehip;
+
+extern "C" size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int method,
+                                                int save_for_backward) {
+  if (!f || batch <= 0 || n_times <= 0 || f->n_convs < 1) return 0;
+  return FixedLayout(f, batch, n_times, method, save_for_backward).total;
+}
+
+extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
+                                   int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+  int rc = check_common(f, method, t_host, n_times, batch, "odeint_fixed");
+  if (rc != ODEHIP_OK) return rc;
+  ODEHIP_REQUIRE(z0_nchw && out_nchw && workspace, "odeint_fixed: null pointer");
+  const FixedLayout L(f, batch, n_times, method, save_for_backward);
+  ODEHIP_REQUIRE(workspace_bytes >= L.total, "odeint_fixed: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+  hipStream_t stream = (hipStream_t)stream_;
+  void* ws = workspace;
+  const size_t st_b = (size_t)batch * L.C * kPix * 4, st_f = st_b / 4;
+  float* hdev = L.p(ws, L.off_h);
+  float* ping = L.p(ws, L.off_ping);
+  float* pong = L.p(ws, L.off_pong);
+  float* k[3] = {L.p(ws, L.off_k), L.p(ws, L.off_k + L.st), L.p(ws, L.off_k + 2 * L.st)};
+
+  ODEHIP_CHECK_HIP(hipMemcpyAsync(out_nchw, z0_nchw, st_b, hipMemcpyDeviceToDevice, stream));  // solution[0] = y0
+  rc = odehip_nchw_to_q4(z0_nchw, L.y(ws, 0), batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  if (n_times == 1) return ODEHIP_OK;
+
+  // step sizes: dt = t1 - t0 in float64, rounded to fp32 when it meets the state (torchdiffeq semantics)
+  float hbuf[4096];
+  for (int i = 0; i + 1 < n_times; ++i) hbuf[i] = (float)(t_host[i + 1] - t_host[i]);
+  rc = upload_floats(hdev, hbuf, n_times - 1, stream);
+  if (rc != ODEHIP_OK) return rc;
+
+  float* hidv[ODEHIP_MAX_LAYERS];
+  for (int n = 0; n + 1 < n_times; ++n) {
+    const float* y = L.y(ws, n);
+    float* ynew = L.y(ws, n + 1);
+    float* ynew_nchw = out_nchw + (size_t)(n + 1) * st_f;
+    // stage input / hidden-activation buffers of stage s (distinct per evaluation when saving)
+    auto xin = [&](int s) { return save_for_backward ? L.xin(ws, n, s) : L.p(ws, L.off_xs); };
+    auto run = [&](int s, const float* x, const CombineArgs& c) {
+      float* const* hp = nullptr;
+      if (save_for_backward) {
+        for (int l = 0; l < L.NH; ++l) hidv[l] = L.hidden(ws, n, s, l);
+        hp = hidv;
+      }
+      return enqueue_f_saving(f, x, batch, hp, ping, pong, &c, nullptr, nullptr, stream);
+    };
+    CombineArgs c;
+    memset(&c, 0, sizeof(c));
+    c.y = y;
+    c.h_ptr = hdev + n;
+    c.k_scale = 1.0f;
+    if (method == ODEHIP_EULER) {  // y1 = y + h*f(y)
+      c.c2[0] = 1.0f;
+      c.out2 = ynew;
+      c.out2_nchw = ynew_nchw;
+      if ((rc = run(0, y, c)) != ODEHIP_OK) return rc;
+    } else if (method == ODEHIP_MIDPOINT) {  // x = y + h/2*k1 ; y1 = y + h*f(x)
+      c.c1[0] = 0.5f;
+      c.out1 = xin(1);
+      if ((rc = run(0, y, c)) != ODEHIP_OK) return rc;
+      c.c1[0] = 0.0f;
+      c.out1 = nullptr;
+      c.c2[0] = 1.0f;
+      c.out2 = ynew;
+      c.out2_nchw = ynew_nchw;
+      if ((rc = run(1, xin(1), c)) != ODEHIP_OK) return rc;
+    } else {  // 3/8 rule (torchdiffeq rk4_alt_step_func)
+      const float third = 1.0f / 3.0f;
+      c.k_out = k[0];  // k1 = f(y); x2 = y + h*(k1/3)
+      c.c1[0] = third;
+      c.out1 = xin(1);
+      if ((rc = run(0, y, c)) != ODEHIP_OK) return rc;
+      c.n_prev = 1;  // k2 = f(x2); x3 = y + h*(k2 - k1/3)
+      c.k_prev[0] = k[0];
+      c.k_out = k[1];
+      c.c1[0] = -third;
+      c.c1[1] = 1.0f;
+      c.out1 = xin(2);
+      if ((rc = run(1, xin(1), c)) != ODEHIP_OK) return rc;
+      c.n_prev = 2;  // k3 = f(x3); x4 = y + h*(k1 - k2 + k3)
+      c.k_prev[1] = k[1];
+      c.k_out = k[2];
+      c.c1[0] = 1.0f;
+      c.c1[1] = -1.0f;
+      c.c1[2] = 1.0f;
+      c.out1 = xin(3);
+      if ((rc = run(2, xin(2), c)) != ODEHIP_OK) return rc;
+      c.n_prev = 3;  // k4 = f(x4); y1 = y + h*(k1 + 3(k2+k3) + k4)/8
+      c.k_prev[2] = k[2];
+      c.k_out = nullptr;
+      c.out1 = nullptr;
+      c.c2[0] = 0.125f;
+      c.c2[1] = 0.375f;
+      c.c2[2] = 0.375f;
+      c.c2[3] = 0.125f;
+      c.out2 = ynew;
+      c.out2_nchw = ynew_nchw;
+      if ((rc = run(3, xin(3), c)) != ODEHIP_OK) return rc;
+    }
+  }
+  return ODEHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of odehip_odeint_fixed(save_for_backward = 1) on the SAME workspace.
+//   f_dgrad: the stack of input-gradient convs, f_dgrad->w_packed[l] = pack(W_l, transpose_flip = 1), in the
+//            forward layer order; bias pointers unused.
+//   grad_out (T,B,C,16,16) NCHW -> grad_z0 (B,C,16,16) NCHW, grad_w[l] (OIHW), grad_b[l].
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method,
+                                            const double* t_host, int n_times, int batch, const float* grad_out_nchw,
+                                            float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, void* workspace,
+                                            size_t workspace_bytes, void* stream_) {
+  int rc = check_common(f, method, t_host, n_times, batch, "odeint_fixed_backward");
+  if (rc != ODEHIP_OK) return rc;
+  ODEHIP_REQUIRE(f_dgrad && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace, "odeint_fixed_backward: null pointer");
+  for (int l = 0; l <= f->n_convs; ++l)
+    ODEHIP_REQUIRE(f->channels[l] == 64, "odeint_fixed_backward: only 64-channel dynamics are supported (channels[%d] = %d)", l,
+                   f->channels[l]);
+  ODEHIP_REQUIRE(f->ks == 3, "odeint_fixed_backward: 3x3 dynamics only");
+  for (int l = 0; l < f->n_convs; ++l)
+    ODEHIP_REQUIRE(f_dgrad->w_packed[l] && grad_w[l] && grad_b[l], "odeint_fixed_backward: layer %d has null pointers", l);
+  const FixedLayout L(f, batch, n_times, method, 1);
+  ODEHIP_REQUIRE(workspace_bytes >= L.total, "odeint_fixed_backward: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  void* ws = workspace;
+  const int NH = L.NH, S = L.S, NL = f->n_convs;
+  const size_t st_b = (size_t)batch * L.C * kPix * 4;
+  const long long n4 = (long long)(st_b / 16);
+  float* hdev = L.p(ws, L.off_h);
+  float* gy = L.p(ws, L.off_gy);
+  float* gbuf[2] = {L.p(ws, L.off_g2), L.p(ws, L.off_g2 + L.st)};
+
+  rc = odehip_nchw_to_q4(grad_out_nchw, L.go(ws, 0), n_times * batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  if (n_times == 1) {
+    ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_z0_nchw, grad_out_nchw, st_b, hipMemcpyDeviceToDevice, stream));
+    for (int l = 0; l < NL; ++l) {
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)64 * 64 * 9 * 4, stream));
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_b[l], 0, 64 * 4, stream));
+    }
+    return ODEHIP_OK;
+  }
+
+  // dgrad chain of evaluation (n, s): GP[n][s][NH] (gradient w.r.t. k) -> ... -> gx, consumed by `targets`
+  auto chain = [&](int n, int s, const BwdArgs& last) -> int {
+    for (int l = NL - 1; l >= 0; --l) {
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.src1 = L.gp(ws, n, s, l);          // gradient w.r.t. the output of conv l
+      a.q1 = a.qin = f->channels[l + 1] / 4;
+      a.qout = f->channels[l] / 4;
+      a.w_packed = f_dgrad->w_packed[l];
+      a.batch = batch;
+      if (l > 0) {
+        a.combine = 2;
+        a.bwd.mask_src = L.hidden(ws, n, s, l - 1);  // ReLU output that fed conv l
+        a.bwd.sc_c = 1.0f;
+        a.dst = L.gp(ws, n, s, l - 1);
+      } else {
+        a.combine = 3;
+        a.bwd = last;
+      }
+      int r = launch_conv(a, f->ks, stream);
+      if (r != ODEHIP_OK) return r;
+    }
+    return ODEHIP_OK;
+  };
+  auto tgt = [](float* out, const float* sa, float a_c, float a_h, const float* sb, float b_c, float b_h, float g_c, float g_h) {
+    BwdTarget t;
+    t.out = out; t.srcA = sa; t.srcB = sb;
+    t.a_c = a_c; t.a_h = a_h; t.b_c = b_c; t.b_h = b_h; t.g_c = g_c; t.g_h = g_h;
+    return t;
+  };
+
+  const int last_s = S - 1;
+  const float wlast = method == ODEHIP_RK4 ? 0.125f : 1.0f;  // weight of the last stage's k in the step
+  // seed: gradient w.r.t. the last stage's k of the last interval = wlast * h * grad_out[T-1]
+  hipLaunchKernelGGL(scale_kernel, dim3(1024), dim3(256), 0, stream, L.gp(ws, n_times - 2, last_s, NH), L.go(ws, n_times - 1), 0.0f,
+                     wlast, hdev + (n_times - 2), n4);
+  const float* g = L.go(ws, n_times - 1);  // total gradient w.r.t. y[n+1]
+  for (int n = n_times - 2; n >= 0; --n) {
+    float* gnext = gbuf[n & 1];
+    // epilogue of the FIRST stage's chain: closes the interval and seeds the next one (which uses h[n-1])
+    auto close_interval = [&](const float* gy_src) {
+      BwdArgs w;
+      memset(&w, 0, sizeof(w));
+      if (n > 0) {
+        w.h_ptr = hdev + (n - 1);
+        w.n_targets = 2;
+        w.tgt[0] = tgt(gnext, gy_src, 1.f, 0.f, L.go(ws, n), 1.f, 0.f, 1.f, 0.f);
+        w.tgt[1] = tgt(L.gp(ws, n - 1, last_s, NH), gy_src, 0.f, wlast, L.go(ws, n), 0.f, wlast, 0.f, wlast);
+      } else {
+        w.n_targets = 1;
+        w.tgt[0] = tgt(gnext, gy_src, 1.f, 0.f, L.go(ws, 0), 1.f, 0.f, 1.f, 0.f);
+      }
+      return w;
+    };
+    BwdArgs w;
+    if (method == ODEHIP_EULER) {
+      // y1 = y + h k1:  gk1 = h g (already seeded), gy = g
+      w = close_interval(g);
+      if ((rc = chain(n, 0, w)) != ODEHIP_OK) return rc;
+    } else if (method == ODEHIP_MIDPOINT) {
+      // x = y + h/2 k1, y1 = y + h k2:  gk2 = h g (seeded); gx2 -> gy = g + gx2, gk1 = h/2 gx2
+      memset(&w, 0, sizeof(w));
+      w.h_ptr = hdev + n;
+      w.n_targets = 2;
+      w.tgt[0] = tgt(gy, g, 1.f, 0.f, nullptr, 0.f, 0.f, 1.f, 0.f);
+      w.tgt[1] = tgt(L.gp(ws, n, 0, NH), nullptr, 0.f, 0.f, nullptr, 0.f, 0.f, 0.f, 0.5f);
+      if ((rc = chain(n, 1, w)) != ODEHIP_OK) return rc;
+      w = close_interval(gy);
+      if ((rc = chain(n, 0, w)) != ODEHIP_OK) return rc;
+    } else {
+      const float third = 1.0f / 3.0f;
+      float* gk1 = L.gp(ws, n, 0, NH);
+      float* gk2 = L.gp(ws, n, 1, NH);
+      float* gk3 = L.gp(ws, n, 2, NH);
+      // stage 4 (gk4 = h/8 g seeded): gx4 -> gy = g + gx4; gk3 = 3h/8 g + h gx4; gk2 = 3h/8 g - h gx4; gk1 = h/8 g + h gx4
+      memset(&w, 0, sizeof(w));
+      w.h_ptr = hdev + n;
+      w.n_targets = 4;
+      w.tgt[0] = tgt(gy, g, 1.f, 0.f, nullptr, 0.f, 0.f, 1.f, 0.f);
+      w.tgt[1] = tgt(gk3, g, 0.f, 0.375f, nullptr, 0.f, 0.f, 0.f, 1.f);
+      w.tgt[2] = tgt(gk2, g, 0.f, 0.375f, nullptr, 0.f, 0.f, 0.f, -1.f);
+      w.tgt[3] = tgt(gk1, g, 0.f, 0.125f, nullptr, 0.f, 0.f, 0.f, 1.f);
+      if ((rc = chain(n, 3, w)) != ODEHIP_OK) return rc;
+      // stage 3: gx3 -> gy += gx3; gk2 += h gx3; gk1 -= h/3 gx3
+      w.n_targets = 3;
+      w.tgt[0] = tgt(gy, gy, 1.f, 0.f, nullptr, 0.f, 0.f, 1.f, 0.f);
+      w.tgt[1] = tgt(gk2, gk2, 1.f, 0.f, nullptr, 0.f, 0.f, 0.f, 1.f);
+      w.tgt[2] = tgt(gk1, gk1, 1.f, 0.f, nullptr, 0.f, 0.f, 0.f, -third);
+      if ((rc = chain(n, 2, w)) != ODEHIP_OK) return rc;
+      // stage 2: gx2 -> gy += gx2; gk1 += h/3 gx2
+      w.n_targets = 2;
+      w.tgt[0] = tgt(gy, gy, 1.f, 0.f, nullptr, 0.f, 0.f, 1.f, 0.f);
+      w.tgt[1] = tgt(gk1, gk1, 1.f, 0.f, nullptr, 0.f, 0.f, 0.f, third);
+      if ((rc = chain(n, 1, w)) != ODEHIP_OK) return rc;
+      // stage 1: gx1 -> g(y[n]) = gy + gx1 + grad_out[n]
+      w = close_interval(gy);
+      if ((rc = chain(n, 0, w)) != ODEHIP_OK) return rc;
+    }
+    g = gnext;
+  }
+  rc = odehip_q4_to_nchw(g, grad_z0_nchw, batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+
+  // ---- weight / bias gradients: one launch per layer over all (T-1)*S evaluations
+  const int n_eval = (n_times - 1) * S;
+  ODEHIP_REQUIRE(n_eval <= 32 * 64, "odeint_fixed_backward: too many evaluations (%d)", n_eval);
+  WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
+  float* slabs = L.p(ws, L.off_slab);
+  for (int l = 0; l < NL && !(g_debug_flags & 32); ++l) {
+    // table[e] = (GP[n][s][l], A[n][s][l]); two u64 per entry, uploaded through kernel arguments
+    for (int o = 0; o < 2 * n_eval; o += 32) {
+      PtrPack pk;
+      const int m = 2 * n_eval - o < 32 ? 2 * n_eval - o : 32;
+      for (int i = 0; i < m; ++i) {
+        const int e = (o + i) / 2, n = e / S, s = e % S;
+        const float* ptr = ((o + i) & 1) ? (l == 0 ? L.xin(ws, n, s) : L.hidden(ws, n, s, l - 1)) : L.gp(ws, n, s, l);
+        pk.v[i] = (unsigned long long)(uintptr_t)ptr;
+      }
+      hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
+    }
+    rc = launch_wgrad64(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], stream);
+    if (rc != ODEHIP_OK) return rc;
+  }
+  return ODEHIP_OK;
+}

@@ -56,6 +56,24 @@ struct CombineArgs {
   float rtol, atol;
 };
 
+// ---- epilogues of the input-gradient (dgrad) convolutions of the backward sweep
+//   combine == 2: dst = scale * acc * (mask_src > 0)            (ReLU backward fused; scale = sc_c + sc_h*h)
+//   combine == 3: gx = acc; up to 4 targets  out_t = (a_c+a_h*h)*srcA_t + (b_c+b_h*h)*srcB_t + (g_c+g_h*h)*gx
+//                 (the reverse Runge-Kutta bookkeeping: gy += gx, gk_j += c*h*gx, next interval's seed, ...)
+struct BwdTarget {
+  float* out;
+  const float* srcA;
+  const float* srcB;
+  float a_c, a_h, b_c, b_h, g_c, g_h;
+};
+struct BwdArgs {
+  const float* mask_src;
+  float sc_c, sc_h;
+  int n_targets;
+  BwdTarget tgt[4];
+  const float* h_ptr;
+};
+
 struct ConvArgs {
   const float* src1;
   const float* src2;
@@ -67,11 +85,12 @@ struct ConvArgs {
   int qout;    // output quads (cout / 4)
   int batch;
   int relu;
-  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue
+  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue; 2/3: BwdArgs epilogues
   int debug;   // diagnostic ablation bits (tools/conv_microbench.py): 1 skip DMA, 2 skip MFMA, 4 skip epilogue
   const int* skip;          // if non-null and *skip != 0 the kernel does nothing (adaptive solver already done)
   unsigned long long* dbg;  // debug & 8: per-workgroup stamps (8 x u64 per workgroup)
   CombineArgs cmb;
+  BwdArgs bwd;
 };
 
 int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);

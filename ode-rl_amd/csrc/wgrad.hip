@@ -1,0 +1,161 @@
+// wgrad.hip -- weight/bias gradient of the 3x3 conv layers of f for the whole backward sweep (gfx950, exact fp32).
+//
+//   dW[co][ci][tap] = sum over every evaluation e of f, sample b, pixel p of  GP_e[b][co][p] * A_e[b][ci][p + tap]
+//   db[co]          = sum of GP_e[b][co][p]
+// where A_e is the saved input of the layer and GP_e the gradient w.r.t. its output (both Q4, written by the forward
+// pass with save_for_backward and by the dgrad sweep).  What autograd does through torchdiffeq's ops, restated as ONE
+// launch per layer: workgroup (sample b, split s) walks its share of the evaluations and keeps the full 64x64x9
+// gradient tile in MFMA accumulators, so nothing is reduced through HBM until the very end (one 147 KB slab per
+// workgroup, summed in a fixed order by `wgrad_reduce_kernel`: bitwise reproducible, no float atomics).
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32, K = 4 consecutive pixels of an image row):
+//   A operand: lane (i, kq) reads GP[quad i][pixel p0+kq] (one ds_read_b128 = channels 4i..4i+3); wave w uses channel
+//              4i+w, so the 4 waves split the 64 output channels by channel-within-quad.
+//   B operand: lane (j, kq) reads A[quad j][pixel p0+kq+tap] (b128 = channels 4j..4j+3 = the four N blocks).
+//   One G read + nine A reads feed 36 MFMAs.  LDS planes are padded by 16 B per quad so the 16 quads of a lane
+//   group fall in different bank slots.
+#include <string.h>
+
+#include "odehip_internal.h"
+
+namespace odehip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ODEHIP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+struct WgradPair {
+  const float* g;  // GP_e (B,64,16,16) Q4
+  const float* a;  // A_e  (B,64,16,16) Q4
+};
+
+constexpr int kGPlane = 4096 + 16;       // one quad plane of G in LDS (256 px * 16 B, padded)
+constexpr int kAPlane = 5 * 1024 + 16;   // one quad plane of A in LDS: rows -1..18 (5 DMA pieces), padded
+constexpr int kWgradLds = 16 * kGPlane + 16 * kAPlane;
+
+__global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                         float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const gl = smem;
+  char* const al = smem + 16 * kGPlane;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x, es = blockIdx.y;
+  const int i16 = lane & 15, kq = lane >> 4;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  // per-lane DMA offsets of the A pieces: piece r covers image rows 4r-1 .. 4r+2; out-of-image rows -> zero fill
+  int va[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int row = 4 * r - 1 + (lane >> 4);
+    va[r] = (row >= 0 && row < kHW) ? row * 256 + (lane & 15) * 16 : 0x7fff0000;
+  }
+  const int vg = lane * 16;
+
+  for (int e = es; e < n_eval; e += esplit) {
+    const WgradPair pr = table[e];
+    const __amdgpu_buffer_rsrc_t rg =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.g) + (size_t)b * 64 * kPix, 0, 64 * kPix * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.a) + (size_t)b * 64 * kPix, 0, 64 * kPix * 4, 0x00020000);
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the previous evaluation's tiles
+    // 16 quads x (4 G pieces + 5 A pieces) = 144 DMAs, 36 per wave: wave w loads quads 4w..4w+3
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int q = wave * 4 + qq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ODEHIP_LDS_PTR(gl + q * kGPlane + r * 1024), 16, vg, q * 4096 + r * 1024, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, ODEHIP_LDS_PTR(al + q * kAPlane + r * 1024), 16, va[r], q * 4096, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const char* gbase = gl + i16 * kGPlane + kq * 16;
+    const char* abase = al + i16 * kAPlane + kq * 16;  // LDS row 0 = image row -1
+    for (int y = 0; y < kHW; ++y) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f32x4 gv = *(const f32x4*)(gbase + (y * 16 + 4 * s) * 16);
+        if (wave == 0) bsum += gv;
+        const float ga = wave == 0 ? gv.x : (wave == 1 ? gv.y : (wave == 2 ? gv.z : gv.w));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int dy = t / 3 - 1, dx = t % 3 - 1;
+          f32x4 av = *(const f32x4*)(abase + ((y + 1 + dy) * 16 + 4 * s + dx) * 16);
+          if (dx < 0 && s == 0) {  // pixel x-1 of x = 0: only the kq = 0 lanes
+            const bool kill = kq == 0;
+            av.x = kill ? 0.f : av.x; av.y = kill ? 0.f : av.y; av.z = kill ? 0.f : av.z; av.w = kill ? 0.f : av.w;
+          }
+          if (dx > 0 && s == 3) {  // pixel x+1 of x = 15: only the kq = 3 lanes
+            const bool kill = kq == 3;
+            av.x = kill ? 0.f : av.x; av.y = kill ? 0.f : av.y; av.z = kill ? 0.f : av.z; av.w = kill ? 0.f : av.w;
+          }
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.x, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.y, acc[t][1], 0, 0, 0);
+          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.z, acc[t][2], 0, 0, 0);
+          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.w, acc[t][3], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // slab[(b*esplit+es)] = dW tile in OIHW order (64*64*9) followed by db (64)
+  float* slab = slabs + (size_t)(b * esplit + es) * (64 * 64 * 9 + 64);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * (4 * kq + r) + wave;  // D row = 4*(lane>>4) + r  -> quad index -> channel 4*quad + wave
+        const int ci = 4 * i16 + n;              // D col = lane & 15        -> quad index -> channel 4*quad + n
+        slab[((size_t)co * 64 + ci) * 9 + t] = acc[t][n][r];
+      }
+  if (wave == 0) {
+    // lane (i16, kq) holds the sums over its pixels of channels 4*i16..4*i16+3: fold the four kq lanes
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (kq == 0) slab[64 * 64 * 9 + 4 * i16 + c] = v;
+    }
+  }
+}
+
+// out[i] (+)= sum over slabs, fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int slab_floats,
+                                                           float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= slab_floats) return;
+  float s = 0.0f;
+  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * slab_floats + i];
+  float* dst = i < 64 * 64 * 9 ? dw + i : db + (i - 64 * 64 * 9);
+  *dst = accumulate ? *dst + s : s;
+}
+
+int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
+                   hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad64_kernel, dim3(batch, esplit), dim3(256), kWgradLds, stream, table_dev, n_eval, esplit, slabs);
+  const int sf = 64 * 64 * 9 + 64;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 255) / 256), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, 0);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+}  // namespace odehip

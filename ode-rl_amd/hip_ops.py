@@ -130,7 +130,23 @@ class PackedConvStack:
         d.final_tanh = int(self.final_tanh)
         self.desc = d
         self._stamp = stamp
+        self._dgrad = None
         return d
+
+    def dgrad_desc(self):
+        """Stack of the input-gradient convs (weights packed transposed + flipped), built on first use."""
+        self.refresh()
+        if self._dgrad is None:
+            packed = [pack_conv_weight(c.weight, transpose_flip=True) for c in self.convs]
+            d = _lib.ConvStack()
+            d.n_convs, d.ks = self.desc.n_convs, self.desc.ks
+            for i in range(len(self.convs) + 1):
+                d.channels[i] = self.desc.channels[i]
+            for i, p in enumerate(packed):
+                d.w_packed[i] = p.data_ptr()
+                d.bias[i] = self._bias[i].data_ptr()
+            self._dgrad = (d, packed)
+        return self._dgrad[0]
 
 
 def convstack_forward(stack, y, negate=False):
@@ -149,8 +165,9 @@ def convstack_forward(stack, y, negate=False):
     return out
 
 
-def odeint_fixed(stack, method, z0, t):
-    """Whole fixed-grid trajectory in one C-ABI call.  Returns (T,B,C,16,16)."""
+def odeint_fixed(stack, method, z0, t, save=False):
+    """Whole fixed-grid trajectory in one C-ABI call.  Returns (T,B,C,16,16); with save=True also the private
+    workspace holding every saved activation (input of odeint_fixed_backward)."""
     require_device_tensor(z0, "y0")
     desc = stack.refresh()
     z0 = z0.contiguous()
@@ -161,13 +178,38 @@ def odeint_fixed(stack, method, z0, t):
     n = len(t64)
     lib = _lib.load()
     m = _lib.METHODS[method]
-    nbytes = lib.odehip_odeint_workspace_bytes(ctypes.byref(desc), b, n, m, 0)
-    ws = workspace(("odeint", b, n, m, tuple(desc.channels)), nbytes, z0.device)
+    nbytes = lib.odehip_odeint_workspace_bytes(ctypes.byref(desc), b, n, m, int(save))
+    if save:  # private: it must survive untouched until backward
+        ws = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=z0.device)
+    else:
+        ws = workspace(("odeint", b, n, m, tuple(desc.channels)), nbytes, z0.device)
     out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
     tarr = (ctypes.c_double * n)(*t64)
-    _lib.check(lib.odehip_odeint_fixed(ctypes.byref(desc), m, _ptr(z0), tarr, n, b, _ptr(out), 0, _ptr(ws), ws.numel(),
+    _lib.check(lib.odehip_odeint_fixed(ctypes.byref(desc), m, _ptr(z0), tarr, n, b, _ptr(out), int(save), _ptr(ws), ws.numel(),
                                        _stream()))
-    return out
+    return (out, ws) if save else out
+
+
+def odeint_fixed_backward(stack, method, t, batch, grad_out, ws):
+    """Gradients of the discrete fixed-grid solver: (grad_z0, [grad_w...], [grad_b...])."""
+    require_device_tensor(grad_out, "grad_out")
+    desc = stack.refresh()
+    dg = stack.dgrad_desc()
+    grad_out = grad_out.contiguous()
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n = len(t64)
+    c = desc.channels[0]
+    gz0 = torch.empty((batch, c, 16, 16), dtype=torch.float32, device=grad_out.device)
+    gws = [torch.empty_like(cv.weight) for cv in stack.convs]
+    gbs = [torch.empty_like(cv.bias) for cv in stack.convs]
+    nl = len(gws)
+    gw_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gws])
+    gb_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbs])
+    tarr = (ctypes.c_double * n)(*t64)
+    _lib.check(_lib.load().odehip_odeint_fixed_backward(ctypes.byref(desc), ctypes.byref(dg), _lib.METHODS[method], tarr, n,
+                                                        batch, _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr, _ptr(ws), ws.numel(),
+                                                        _stream()))
+    return gz0, gws, gbs
 
 
 def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):

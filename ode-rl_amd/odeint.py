@@ -85,7 +85,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     hip_ops.require_device_tensor(y0, "y0")
     if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in func.parameters())):
         from .autograd import odeint_with_grad
-        return odeint_with_grad(func, y0, t, rtol, atol, method)
+        return odeint_with_grad(func, y0, t, rtol, atol, method, options)
     return odeint_forward(func, y0, t, rtol, atol, method, options)
 
 
