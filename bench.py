@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1]: 64)")
     p.add_argument("--frames", type=int, default=10, help="output time points (10 -> 9 intervals)")
     p.add_argument("--method", default="rk4")
+    p.add_argument("--train", action="store_true", help="time forward + backward (gradients w.r.t. z0 and all weights)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     return p.parse_args()
@@ -126,18 +127,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            out = solver(z0, t)
-        sync()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(a.steps):
-            out = solver(z0, t)
-        ev1.record()
-        sync()
-        wall = time.perf_counter() - t0
+    gout = torch.randn(T, a.batch, 64, 16, 16, generator=torch.Generator().manual_seed(99)).to(dev) if a.train else None
+
+    def step():
+        if not a.train:
+            with torch.no_grad():
+                return solver(z0, t)
+        zz = z0.detach().requires_grad_(True)
+        f.zero_grad(set_to_none=False)
+        o = solver(zz, t)
+        o.backward(gout)
+        if dist is not None:   # the ONE collective of a training step: flattened-bucket all-reduce of the gradients
+            from ode_rl_amd.dist import allreduce_gradients
+            allreduce_gradients(f.parameters())
+        return o.detach()
+
+    for _ in range(a.warmup):
+        out = step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        out = step()
+    ev1.record()
+    sync()
+    wall = time.perf_counter() - t0
     assert out.shape == (T, a.batch, 64, 16, 16) and bool(torch.isfinite(out).all())
     dev_ms = ev0.elapsed_time(ev1)
 
@@ -149,7 +164,7 @@ def main():
     if rank == 0:
         nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
         n_convs = 5
-        launches = nfe_per_step * n_convs * a.steps
+        launches = nfe_per_step * n_convs * a.steps * (2 if a.train else 1)   # train: + the dgrad conv of every layer
         flop_per_launch = conv_flops([64, 64], a.batch)             # one 64->64 3x3 layer over the batch
         per_launch_s = dev_ms * 1e-3 / launches                      # HIP events, incl. inter-kernel gaps
         achieved = flop_per_launch / per_launch_s / 1e12
@@ -163,7 +178,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
                                    f"({T - 1} intervals), fixed-step {a.method} (3/8 rule), f = 5x conv3x3(64->64)+ReLU, "
-                                   "forward only (BASELINE configs[1])",
+                                   + ("forward + backward (discretise-then-optimise)" if a.train else "forward only (BASELINE configs[1])"),
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_resident_kernel<4>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
