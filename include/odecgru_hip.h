@@ -100,9 +100,11 @@ size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int batch, int n
                                      int save_for_backward);
 
 /* z0: (B,C,16,16) NCHW; t_host: n_times float64 on the HOST, strictly increasing;
- * out: (n_times,B,C,16,16) NCHW, out[0] = z0.  One step per output interval. */
+ * out: (n_times,B,C,16,16) NCHW, out[0] = z0.  One step per output interval.
+ * negate != 0 integrates dz/dt = -f(z): torchdiffeq's handling of a strictly DEcreasing t is to flip the sign of t
+ * and of the dynamics (_impl/odeint.py _check_inputs); the host passes -t here. */
 int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
-                        int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
+                        int n_times, int batch, float* out_nchw, int save_for_backward, int negate, void* workspace,
                         size_t workspace_bytes, void* stream);
 
 /* Backward of odehip_odeint_fixed(save_for_backward = 1), on the SAME workspace (untouched in between).
@@ -162,8 +164,8 @@ size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n
  * max_steps <= 0 means unlimited (torchdiffeq max_num_steps = 2^31-1).
  * Errors: ODEHIP_ENOTCONV (dt underflow / max_steps), ODEHIP_ENAN (non-finite error ratio). */
 int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
-                         float rtol, float atol, double first_step, int max_steps, float* out_nchw, int* stats_host,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         float rtol, float atol, double first_step, int max_steps, int negate, float* out_nchw,
+                         int* stats_host, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -334,8 +334,8 @@ extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int b
 }
 
 extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
-                                    int batch, float rtol, float atol, double first_step, int max_steps, float* out_nchw,
-                                    int* stats_host, void* workspace, size_t workspace_bytes, void* stream_) {
+                                    int batch, float rtol, float atol, double first_step, int max_steps, int negate,
+                                    float* out_nchw, int* stats_host, void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(z0_nchw && t_host && out_nchw && workspace, "odeint_dopri5: null pointer");
@@ -398,7 +398,8 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   // ---- _select_initial_step: f0, d0, d1 -> h0; f(y0 + h0 f0); d2 -> dt
   CombineArgs c;
   memset(&c, 0, sizeof(c));
-  c.k_scale = 1.0f;
+  const float ksc = negate ? -1.0f : 1.0f;
+  c.k_scale = ksc;
   c.k_out = k[0];
   rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
   if (rc != ODEHIP_OK) return rc;
@@ -447,7 +448,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   for (;;) {
     for (int s = 2; s <= 7; ++s) {  // k_s = f(x_s); fused: x_{s+1} = y + h*sum beta_{s+1,j} k_j   (s = 7: error norm)
       memset(&c, 0, sizeof(c));
-      c.k_scale = 1.0f;
+      c.k_scale = ksc;
       c.y = y;
       c.h_ptr = &state->h;
       c.n_prev = s - 1;

@@ -116,9 +116,10 @@ extern "C" size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int b
 }
 
 extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
-                                   int n_times, int batch, float* out_nchw, int save_for_backward, void* workspace,
-                                   size_t workspace_bytes, void* stream_) {
+                                   int n_times, int batch, float* out_nchw, int save_for_backward, int negate,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_common(f, method, t_host, n_times, batch, "odeint_fixed");
+  ODEHIP_REQUIRE(!(negate && save_for_backward), "odeint_fixed: backward through negated dynamics is not supported");
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(z0_nchw && out_nchw && workspace, "odeint_fixed: null pointer");
   const FixedLayout L(f, batch, n_times, method, save_for_backward);
@@ -161,7 +162,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
     memset(&c, 0, sizeof(c));
     c.y = y;
     c.h_ptr = hdev + n;
-    c.k_scale = 1.0f;
+    c.k_scale = negate ? -1.0f : 1.0f;
     if (method == ODEHIP_EULER) {  // y1 = y + h*f(y)
       c.c2[0] = 1.0f;
       c.out2 = ynew;

@@ -165,7 +165,7 @@ def convstack_forward(stack, y, negate=False):
     return out
 
 
-def odeint_fixed(stack, method, z0, t, save=False):
+def odeint_fixed(stack, method, z0, t, save=False, negate=False):
     """Whole fixed-grid trajectory in one C-ABI call.  Returns (T,B,C,16,16); with save=True also the private
     workspace holding every saved activation (input of odeint_fixed_backward)."""
     require_device_tensor(z0, "y0")
@@ -185,8 +185,8 @@ def odeint_fixed(stack, method, z0, t, save=False):
         ws = workspace(("odeint", b, n, m, tuple(desc.channels)), nbytes, z0.device)
     out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
     tarr = (ctypes.c_double * n)(*t64)
-    _lib.check(lib.odehip_odeint_fixed(ctypes.byref(desc), m, _ptr(z0), tarr, n, b, _ptr(out), int(save), _ptr(ws), ws.numel(),
-                                       _stream()))
+    _lib.check(lib.odehip_odeint_fixed(ctypes.byref(desc), m, _ptr(z0), tarr, n, b, _ptr(out), int(save), int(bool(negate)), _ptr(ws),
+                                       ws.numel(), _stream()))
     return (out, ws) if save else out
 
 
@@ -212,7 +212,7 @@ def odeint_fixed_backward(stack, method, t, batch, grad_out, ws):
     return gz0, gws, gbs
 
 
-def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
+def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=False):
     """Adaptive dopri5 trajectory; returns ((T,B,C,16,16), stats dict)."""
     require_device_tensor(z0, "y0")
     desc = stack.refresh()
@@ -229,7 +229,7 @@ def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
     tarr = (ctypes.c_double * n)(*t64)
     stats = (ctypes.c_int * 4)()
     _lib.check(lib.odehip_odeint_dopri5(ctypes.byref(desc), _ptr(z0), tarr, n, b, float(rtol), float(atol), float(first_step or 0.0), int(max_steps),
-                                        _ptr(out), stats, _ptr(ws), ws.numel(), _stream()))
+                                        int(bool(negate)), _ptr(out), stats, _ptr(ws), ws.numel(), _stream()))
     return out, {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3]}
 
 

@@ -92,21 +92,19 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 def odeint_forward(func, y0, t, rtol, atol, method, options=None):
     th = _host_times(t)
     _check_monotone(th)
-    backwards = bool(getattr(func, "_hip_backwards", False))
-    if len(th) > 1 and bool(th[0] > th[1]):
+    negate = False
+    if len(th) > 1 and bool(th[0] > th[1]):  # torchdiffeq: strictly decreasing t => integrate -f on -t
         th = -th
-        backwards = not backwards
-    if backwards:
-        raise NotImplementedError("odeint(HIP): reversed-time integration is not implemented yet")
+        negate = True
     stack = conv_stack_of(func)
     if method in FIXED_GRID:
-        return hip_ops.odeint_fixed(stack, method, y0, th)
+        return hip_ops.odeint_fixed(stack, method, y0, th, negate=negate)
     options = options or {}
     unknown = set(options) - {"first_step", "max_num_steps"}
     if unknown:
         raise ValueError(f"odeint(HIP): unsupported dopri5 options {sorted(unknown)}")
     out, stats = hip_ops.odeint_dopri5(stack, y0, th, rtol, atol, first_step=float(options.get("first_step") or 0.0),
-                                       max_steps=int(options.get("max_num_steps") or 0))
+                                       max_steps=int(options.get("max_num_steps") or 0), negate=negate)
     last_stats.clear()
     last_stats.update(stats)
     return out

@@ -176,3 +176,18 @@ def test_dopri5_forced_rejections(cuda):
         with pytest.raises(AssertionError):
             ode_rl_amd.odeint(f, z0.to(cuda), t, rtol=1e-4, atol=1e-5, method="dopri5",
                               options={"first_step": 3.0, "max_num_steps": 2})
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_decreasing_time_integrates_negated_dynamics(cuda, method):
+    """torchdiffeq flips a strictly decreasing t and the sign of f; integrating forth and back returns to z0."""
+    import ode_rl_amd
+    from oracle import torchdiffeq_ref
+    fa = load_golden("f_A.npz")
+    f = _func_from_golden(fa, cuda, 64, 64, 3, 64)
+    z0 = torch.randn(2, 64, 16, 16, generator=torch.Generator().manual_seed(8)) * 0.5
+    t = torch.tensor([0.9, 0.6, 0.55, 0.1], dtype=torch.float64)
+    with torch.no_grad():
+        got = ode_rl_amd.odeint(f, z0.to(cuda), t, rtol=1e-4, atol=1e-5, method=method)
+        ref = torchdiffeq_ref.odeint(_oracle_f(fa), z0, t, rtol=1e-4, atol=1e-5, method=method)
+    assert rel_l2(got, ref) <= 1e-4

@@ -1,0 +1,66 @@
+"""VidODE-shaped latents (configs.yaml:709-721, models/VidODE.py:61-86): 128-channel state,
+f = Conv3x3 128->64, 64->64, 64->64, 64->128 (n_layers 2), ODE-ConvGRU cell with 128 channels (5x5 convs 256->256 and
+256->128, GroupNorm 8 / 4 groups).  The flow/warp decoder of VidODE is out of scope (section 8 f3); what is checked is
+the latent path: encoder cell -> z0 -> solver, against the oracle.  Tolerances as in the ODEConvGRU-shaped tests."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _f_v():
+    import ode_rl_amd
+    torch.manual_seed(21)
+    f = ode_rl_amd.ODEFunc(n_inputs=128, n_outputs=128, n_layers=2, n_units=64, downsize=False, nonlinear="relu", final_act=False)
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    return f, sd
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_solver_on_vidode_latents(cuda, method):
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    f, sd = _f_v()
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+    assert [tuple(w.shape[:2]) for w in ws] == [(64, 128), (64, 64), (64, 64), (128, 64)]
+    z0 = torch.randn(3, 128, 16, 16, generator=torch.Generator().manual_seed(4)) * 0.5
+    t = torch.arange(10, 16, dtype=torch.float64) / 20
+    st = {}
+    with torch.no_grad():
+        ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs), z0, t, rtol=1e-4, atol=1e-5, method=method, stats=st)
+        got = ode_rl_amd.DiffEqSolver(f.to(cuda), method, device=cuda)(z0.to(cuda), t.to(cuda))
+    assert got.shape == (6, 3, 128, 16, 16)
+    assert rel_l2(got, ref) <= 1e-4
+    if method == "dopri5":
+        s = ode_rl_amd.last_stats
+        assert (s["nfe"], s["n_accept"], s["n_reject"]) == (st["nfe"], st.get("n_accept", 0), st.get("n_reject", 0))
+
+
+def test_encoder_on_vidode_latents(cuda):
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    f, _ = _f_v()
+    torch.manual_seed(22)
+    enc = ode_rl_amd.ODEConvGRUCell(f, None, (16, 16), 128)
+    with torch.no_grad():
+        for k, p in enc.state_dict().items():
+            if "cgru_cell" in k and ".1." in k:
+                p.copy_(torch.randn_like(p) * 0.3 + (1.0 if k.endswith("weight") else 0.0))
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    ws, bs = rm.split_convnet_state(sd, "ode_func.gradient_net.")
+    cell = {k[len("cgru_cell."):]: v for k, v in sd.items() if k.startswith("cgru_cell.")}
+    head = {k[len("transform_z0."):]: v for k, v in sd.items() if k.startswith("transform_z0.")}
+    assert cell["conv_gates.0.weight"].shape == (256, 256, 5, 5) and cell["conv_can.0.weight"].shape == (128, 256, 5, 5)
+    inp = torch.randn(3, 2, 128, 16, 16, generator=torch.Generator().manual_seed(5)) * 0.5
+    t = torch.arange(3, dtype=torch.float64) / 6
+    with torch.no_grad():
+        mean_r, std_r, lat_r = rm.ode_convgru_encode(inp, t, rm.ode_func(ws, bs), cell, head)
+        enc = enc.to(cuda)
+        mean, std = enc(inp.to(cuda), t.to(cuda))
+        _, lat = enc.run_ode_conv_gru(inp.to(cuda), t.to(cuda))
+    assert mean.shape == (2, 128, 16, 16)
+    assert rel_l2(lat, lat_r) <= 5e-5
+    assert rel_l2(mean, mean_r) <= 5e-5 and rel_l2(std, std_r) <= 5e-5
