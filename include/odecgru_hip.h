@@ -116,6 +116,15 @@ int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convsta
                                  int n_times, int batch, const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
                                  float* const* grad_b, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Adjoint backward: torchdiffeq `odeint_adjoint` semantics (new capability; the reference uses plain autograd).  For
+ * i = T-1..1 the augmented state (y, a_y, a_theta) is integrated from t[i] back to t[i-1] with one step of `method`,
+ * y is reset to the stored y[i-1], a_y += grad_out[i-1].  y_traj = the forward output (T,B,C,16,16).  Needs no saved
+ * activations; workspace size = odehip_odeint_workspace_bytes(..., save_for_backward = 1).  64-channel 3x3 dynamics. */
+int odehip_odeint_adjoint_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method, const double* t_host,
+                                   int n_times, int batch, const float* y_traj_nchw, const float* grad_out_nchw,
+                                   float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* ---- ConvGRU cell and the ODE-ConvGRU encoder (modules/ConvGRUCell.py:55-86, modules/ODEConvGRUCell.py:32-78) ---- */
 
 typedef struct odehip_convgru_cell {

@@ -20,6 +20,8 @@ namespace odehip {
 struct WgradPair {
   const float* g;
   const float* a;
+  float scale;
+  float pad_[3];
 };
 int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
                    hipStream_t stream);
@@ -102,6 +104,45 @@ static int check_common(const odehip_convstack* f, int method, const double* t_h
   for (int i = 1; i < n_times; ++i)
     ODEHIP_REQUIRE(t_host[i] > t_host[i - 1], "%s: t must be strictly increasing (t[%d]=%g, t[%d]=%g)", who, i - 1, t_host[i - 1],
                    i, t_host[i]);
+  return ODEHIP_OK;
+}
+
+// dW_l, db_l = sum over evaluations e = (n, s) of scale_e * wgrad(GP[n][s][l], A[n][s][l]); one launch per layer.
+// A[n][s][0] is the stage input: y[n] (forward sweep) or y[n+1] (adjoint, integrating backwards) for s = 0.
+static int wgrad_all_layers(const odehip_convstack* f, const FixedLayout& L, void* ws, int n_times, int batch, bool adjoint,
+                            const float* eval_scale /* host, (T-1)*S entries or null = 1 */, float* const* grad_w,
+                            float* const* grad_b, hipStream_t stream) {
+  const int S = L.S, NL = f->n_convs;
+  const int n_eval = (n_times - 1) * S;
+  ODEHIP_REQUIRE(n_eval <= 32 * 64, "odeint backward: too many evaluations (%d)", n_eval);
+  WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
+  float* slabs = L.p(ws, L.off_slab);
+  for (int l = 0; l < NL && !(g_debug_flags & 32); ++l) {
+    // 4 u64 per table entry (g, a, scale bits, 0), uploaded through kernel arguments
+    for (int o = 0; o < 4 * n_eval; o += 32) {
+      PtrPack pk;
+      const int m = 4 * n_eval - o < 32 ? 4 * n_eval - o : 32;
+      for (int i = 0; i < m; ++i) {
+        const int e = (o + i) / 4, n = e / S, s = e % S, field = (o + i) & 3;
+        unsigned long long v = 0;
+        if (field == 0) {
+          v = (unsigned long long)(uintptr_t)L.gp(ws, n, s, l);
+        } else if (field == 1) {
+          const float* a = l > 0 ? L.hidden(ws, n, s, l - 1) : (s > 0 ? L.xin(ws, n, s) : L.y(ws, adjoint ? n + 1 : n));
+          v = (unsigned long long)(uintptr_t)a;
+        } else if (field == 2) {
+          const float sc = eval_scale ? eval_scale[e] : 1.0f;
+          unsigned u;
+          memcpy(&u, &sc, 4);
+          v = u;
+        }
+        pk.v[i] = v;
+      }
+      hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
+    }
+    int rc = launch_wgrad64(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], stream);
+    if (rc != ODEHIP_OK) return rc;
+  }
   return ODEHIP_OK;
 }
 
@@ -360,24 +401,189 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
   if (rc != ODEHIP_OK) return rc;
 
   // ---- weight / bias gradients: one launch per layer over all (T-1)*S evaluations
-  const int n_eval = (n_times - 1) * S;
-  ODEHIP_REQUIRE(n_eval <= 32 * 64, "odeint_fixed_backward: too many evaluations (%d)", n_eval);
-  WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
-  float* slabs = L.p(ws, L.off_slab);
-  for (int l = 0; l < NL && !(g_debug_flags & 32); ++l) {
-    // table[e] = (GP[n][s][l], A[n][s][l]); two u64 per entry, uploaded through kernel arguments
-    for (int o = 0; o < 2 * n_eval; o += 32) {
-      PtrPack pk;
-      const int m = 2 * n_eval - o < 32 ? 2 * n_eval - o : 32;
-      for (int i = 0; i < m; ++i) {
-        const int e = (o + i) / 2, n = e / S, s = e % S;
-        const float* ptr = ((o + i) & 1) ? (l == 0 ? L.xin(ws, n, s) : L.hidden(ws, n, s, l - 1)) : L.gp(ws, n, s, l);
-        pk.v[i] = (unsigned long long)(uintptr_t)ptr;
-      }
-      hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
+  return wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/false, nullptr, grad_w, grad_b, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adjoint backward (torchdiffeq `odeint_adjoint` semantics, _impl/adjoint.py; NEW capability -- the reference itself
+// never uses it: modules/DiffEqSolver.py:9).  For i = T-1 .. 1 the augmented state (y, a_y, a_theta) is integrated
+// from t[i] back to t[i-1] with ONE step of the same fixed-grid method on the negated dynamics (torchdiffeq flips a
+// decreasing time grid), y is then reset to the stored forward value y[i-1] and a_y += grad_out[i-1].
+//   d a_y / dt     = -J_f(y)^T a_y          -> the dgrad chain (same MFMA conv kernel, transposed+flipped weights)
+//   d a_theta / dt = -(df/dtheta)^T a_y     -> wgrad over every stage of every interval, weighted dt*b_s, one launch
+// The stages of y are recomputed from y[i] (nothing saved by the forward pass except the trajectory itself).
+// Workspace: odehip_odeint_workspace_bytes(..., save_for_backward = 1).
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method,
+                                              const double* t_host, int n_times, int batch, const float* y_traj_nchw,
+                                              const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
+                                              float* const* grad_b, void* workspace, size_t workspace_bytes, void* stream_) {
+  int rc = check_common(f, method, t_host, n_times, batch, "odeint_adjoint_backward");
+  if (rc != ODEHIP_OK) return rc;
+  ODEHIP_REQUIRE(f_dgrad && y_traj_nchw && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace,
+                 "odeint_adjoint_backward: null pointer");
+  for (int l = 0; l <= f->n_convs; ++l)
+    ODEHIP_REQUIRE(f->channels[l] == 64, "odeint_adjoint_backward: only 64-channel dynamics are supported (channels[%d] = %d)", l,
+                   f->channels[l]);
+  ODEHIP_REQUIRE(f->ks == 3, "odeint_adjoint_backward: 3x3 dynamics only");
+  const FixedLayout L(f, batch, n_times, method, 1);
+  ODEHIP_REQUIRE(workspace_bytes >= L.total, "odeint_adjoint_backward: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  void* ws = workspace;
+  const int NH = L.NH, S = L.S, NL = f->n_convs;
+  const size_t st_b = (size_t)batch * L.C * kPix * 4;
+  float* hdev = L.p(ws, L.off_h);
+  float* ping = L.p(ws, L.off_ping);
+  float* pong = L.p(ws, L.off_pong);
+  float* k[3] = {L.p(ws, L.off_k), L.p(ws, L.off_k + L.st), L.p(ws, L.off_k + 2 * L.st)};
+  float* q3 = L.p(ws, L.off_gy);             // partial sums of the a_y stages (see below)
+  float* q4 = L.p(ws, L.off_g2);
+  float* rr = L.p(ws, L.off_g2 + L.st);
+
+  rc = odehip_nchw_to_q4(y_traj_nchw, L.y(ws, 0), n_times * batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  rc = odehip_nchw_to_q4(grad_out_nchw, L.go(ws, 0), n_times * batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  if (n_times == 1) {
+    ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_z0_nchw, grad_out_nchw, st_b, hipMemcpyDeviceToDevice, stream));
+    for (int l = 0; l < NL; ++l) {
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)64 * 64 * 9 * 4, stream));
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_b[l], 0, 64 * 4, stream));
     }
-    rc = launch_wgrad64(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], stream);
-    if (rc != ODEHIP_OK) return rc;
+    return ODEHIP_OK;
   }
-  return ODEHIP_OK;
+  float hbuf[4096];
+  for (int i = 0; i + 1 < n_times; ++i) hbuf[i] = (float)(t_host[i + 1] - t_host[i]);  // dt of the flipped grid, > 0
+  rc = upload_floats(hdev, hbuf, n_times - 1, stream);
+  if (rc != ODEHIP_OK) return rc;
+
+  float* hidv[ODEHIP_MAX_LAYERS];
+  auto run_f = [&](int n, int s, const float* x, const CombineArgs& c) {  // f at stage s, activations kept
+    for (int l = 0; l < NH; ++l) hidv[l] = L.hidden(ws, n, s, l);
+    return enqueue_f_saving(f, x, batch, hidv, ping, pong, &c, nullptr, nullptr, stream);
+  };
+  auto chain = [&](int n, int s, const BwdArgs& last) -> int {  // K^a = J_f(Y_s)^T A_s, A_s = GP[n][s][NH]
+    for (int l = NL - 1; l >= 0; --l) {
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.src1 = L.gp(ws, n, s, l);
+      a.q1 = a.qin = f->channels[l + 1] / 4;
+      a.qout = f->channels[l] / 4;
+      a.w_packed = f_dgrad->w_packed[l];
+      a.batch = batch;
+      if (l > 0) {
+        a.combine = 2;
+        a.bwd.mask_src = L.hidden(ws, n, s, l - 1);
+        a.bwd.sc_c = 1.0f;
+        a.dst = L.gp(ws, n, s, l - 1);
+      } else {
+        a.combine = 3;
+        a.bwd = last;
+      }
+      int r = launch_conv(a, f->ks, stream);
+      if (r != ODEHIP_OK) return r;
+    }
+    return ODEHIP_OK;
+  };
+  auto tgt = [](float* out, const float* sa, float a_c, const float* sb, float b_c, float g_h) {
+    BwdTarget t;
+    t.out = out; t.srcA = sa; t.srcB = sb;
+    t.a_c = a_c; t.a_h = 0.f; t.b_c = b_c; t.b_h = 0.f; t.g_c = 0.f; t.g_h = g_h;
+    return t;
+  };
+
+  // seed: a_y = grad_out[T-1] is the stage-1 adjoint of the last interval
+  ODEHIP_CHECK_HIP(hipMemcpyAsync(L.gp(ws, n_times - 2, 0, NH), L.go(ws, n_times - 1), st_b, hipMemcpyDeviceToDevice, stream));
+  float scales[4096];
+  ODEHIP_REQUIRE((n_times - 1) * S <= 4096, "odeint_adjoint_backward: too many evaluations");
+  float* a_final = L.p(ws, L.off_xs);
+  for (int n = n_times - 2; n >= 0; --n) {
+    const float* y = L.y(ws, n + 1);                       // integrate from t[n+1] back to t[n]
+    const float* a = L.gp(ws, n, 0, NH);                   // a_y at t[n+1]
+    float* a_next = n > 0 ? L.gp(ws, n - 1, 0, NH) : a_final;  // a_y at t[n] (+ grad_out[n]) seeds the next interval
+    CombineArgs c;
+    memset(&c, 0, sizeof(c));
+    c.y = y;
+    c.h_ptr = hdev + n;
+    c.k_scale = -1.0f;                                     // negated dynamics
+    BwdArgs w;
+    memset(&w, 0, sizeof(w));
+    w.h_ptr = hdev + n;
+    const float dt = hbuf[n];
+    if (method == ODEHIP_EULER) {
+      scales[n * S + 0] = dt;
+      if ((rc = run_f(n, 0, y, c)) != ODEHIP_OK) return rc;
+      w.n_targets = 1;
+      w.tgt[0] = tgt(a_next, a, 1.f, L.go(ws, n), 1.f, 1.f);            // a + dt K1 + grad_out[n]
+      if ((rc = chain(n, 0, w)) != ODEHIP_OK) return rc;
+    } else if (method == ODEHIP_MIDPOINT) {
+      scales[n * S + 0] = 0.0f;                                         // b = (0, 1)
+      scales[n * S + 1] = dt;
+      c.c1[0] = 0.5f;
+      c.out1 = L.xin(ws, n, 1);                                         // Y2 = y + dt/2 k1'
+      if ((rc = run_f(n, 0, y, c)) != ODEHIP_OK) return rc;
+      w.n_targets = 1;
+      w.tgt[0] = tgt(L.gp(ws, n, 1, NH), a, 1.f, nullptr, 0.f, 0.5f);   // A2 = a + dt/2 K1
+      if ((rc = chain(n, 0, w)) != ODEHIP_OK) return rc;
+      c.c1[0] = 0.f;
+      c.out1 = nullptr;
+      if ((rc = run_f(n, 1, L.xin(ws, n, 1), c)) != ODEHIP_OK) return rc;
+      w.tgt[0] = tgt(a_next, a, 1.f, L.go(ws, n), 1.f, 1.f);            // a + dt K2 + grad_out[n]
+      if ((rc = chain(n, 1, w)) != ODEHIP_OK) return rc;
+    } else {
+      const float third = 1.0f / 3.0f;
+      scales[n * S + 0] = dt * 0.125f;
+      scales[n * S + 1] = dt * 0.375f;
+      scales[n * S + 2] = dt * 0.375f;
+      scales[n * S + 3] = dt * 0.125f;
+      // stage 1: k1' = -f(y); Y2 = y + dt k1'/3.   K1: A2 = a + dt/3 K1; Q3 = a - dt/3 K1; Q4 = a + dt K1; R = a + dt/8 K1
+      c.k_out = k[0];
+      c.c1[0] = third;
+      c.out1 = L.xin(ws, n, 1);
+      if ((rc = run_f(n, 0, y, c)) != ODEHIP_OK) return rc;
+      w.n_targets = 4;
+      w.tgt[0] = tgt(L.gp(ws, n, 1, NH), a, 1.f, nullptr, 0.f, third);
+      w.tgt[1] = tgt(q3, a, 1.f, nullptr, 0.f, -third);
+      w.tgt[2] = tgt(q4, a, 1.f, nullptr, 0.f, 1.f);
+      w.tgt[3] = tgt(rr, a, 1.f, nullptr, 0.f, 0.125f);
+      if ((rc = chain(n, 0, w)) != ODEHIP_OK) return rc;
+      // stage 2: Y3 = y + dt (k2' - k1'/3).   K2: A3 = Q3 + dt K2; Q4 -= dt K2; R += 3dt/8 K2
+      c.n_prev = 1;
+      c.k_prev[0] = k[0];
+      c.k_out = k[1];
+      c.c1[0] = -third;
+      c.c1[1] = 1.f;
+      c.out1 = L.xin(ws, n, 2);
+      if ((rc = run_f(n, 1, L.xin(ws, n, 1), c)) != ODEHIP_OK) return rc;
+      w.n_targets = 3;
+      w.tgt[0] = tgt(L.gp(ws, n, 2, NH), q3, 1.f, nullptr, 0.f, 1.f);
+      w.tgt[1] = tgt(q4, q4, 1.f, nullptr, 0.f, -1.f);
+      w.tgt[2] = tgt(rr, rr, 1.f, nullptr, 0.f, 0.375f);
+      if ((rc = chain(n, 1, w)) != ODEHIP_OK) return rc;
+      // stage 3: Y4 = y + dt (k1' - k2' + k3').   K3: A4 = Q4 + dt K3; R += 3dt/8 K3
+      c.n_prev = 2;
+      c.k_prev[1] = k[1];
+      c.k_out = nullptr;
+      c.c1[0] = 1.f;
+      c.c1[1] = -1.f;
+      c.c1[2] = 1.f;
+      c.out1 = L.xin(ws, n, 3);
+      if ((rc = run_f(n, 2, L.xin(ws, n, 2), c)) != ODEHIP_OK) return rc;
+      w.n_targets = 2;
+      w.tgt[0] = tgt(L.gp(ws, n, 3, NH), q4, 1.f, nullptr, 0.f, 1.f);
+      w.tgt[1] = tgt(rr, rr, 1.f, nullptr, 0.f, 0.375f);
+      if ((rc = chain(n, 2, w)) != ODEHIP_OK) return rc;
+      // stage 4: only the activations at Y4 are needed (y is reset to the stored y[n]).   K4: a_next = R + dt/8 K4 + grad_out[n]
+      memset(&c, 0, sizeof(c));
+      c.k_scale = -1.0f;
+      c.k_out = k[2];  // k4' itself is unused; the epilogue needs some destination
+      if ((rc = run_f(n, 3, L.xin(ws, n, 3), c)) != ODEHIP_OK) return rc;
+      w.n_targets = 1;
+      w.tgt[0] = tgt(a_next, rr, 1.f, L.go(ws, n), 1.f, 0.125f);
+      if ((rc = chain(n, 3, w)) != ODEHIP_OK) return rc;
+    }
+  }
+  rc = odehip_q4_to_nchw(a_final, grad_z0_nchw, batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  return wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/true, scales, grad_w, grad_b, stream);
 }

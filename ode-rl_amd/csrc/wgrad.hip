@@ -27,6 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WgradPair {
   const float* g;  // GP_e (B,64,16,16) Q4
   const float* a;  // A_e  (B,64,16,16) Q4
+  float scale;     // weight of this evaluation in the sum (1 for discretise-then-optimise; dt*b_s for the adjoint)
+  float pad_[3];
 };
 
 constexpr int kGPlane = 4096 + 16;       // one quad plane of G in LDS (256 px * 16 B, padded)
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
 
   for (int e = es; e < n_eval; e += esplit) {
     const WgradPair pr = table[e];
+    const float esc = pr.scale;
     const __amdgpu_buffer_rsrc_t rg =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.g) + (size_t)b * 64 * kPix, 0, 64 * kPix * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra =
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
     for (int y = 0; y < kHW; ++y) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const f32x4 gv = *(const f32x4*)(gbase + (y * 16 + 4 * s) * 16);
+        const f32x4 gv = *(const f32x4*)(gbase + (y * 16 + 4 * s) * 16) * esc;
         if (wave == 0) bsum += gv;
         const float ga = wave == 0 ? gv.x : (wave == 1 ? gv.y : (wave == 2 ? gv.z : gv.w));
 #pragma unroll
@@ -138,8 +141,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= slab_floats) return;
-  float s = 0.0f;
-  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * slab_floats + i];
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // 8 independent chains: the loads overlap; order is fixed
+  for (int k = 0; k < n_slabs; k += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (k + j < n_slabs) p[j] += slabs[(size_t)(k + j) * slab_floats + i];
+  }
+  const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   float* dst = i < 64 * 64 * 9 ? dw + i : db + (i - 64 * 64 * 9);
   *dst = accumulate ? *dst + s : s;
 }

@@ -233,6 +233,31 @@ def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=
     return out, {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3]}
 
 
+def odeint_adjoint_backward(stack, method, t, y_traj, grad_out):
+    """torchdiffeq odeint_adjoint backward for the fixed-grid methods: (grad_z0, [grad_w...], [grad_b...])."""
+    require_device_tensor(grad_out, "grad_out")
+    require_device_tensor(y_traj, "y_traj")
+    desc = stack.refresh()
+    dg = stack.dgrad_desc()
+    grad_out, y_traj = grad_out.contiguous(), y_traj.contiguous()
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n, b, c = len(t64), y_traj.shape[1], desc.channels[0]
+    lib = _lib.load()
+    m = _lib.METHODS[method]
+    nbytes = lib.odehip_odeint_workspace_bytes(ctypes.byref(desc), b, n, m, 1)
+    ws = workspace(("adjoint", b, n, m, tuple(desc.channels)), nbytes, grad_out.device)
+    gz0 = torch.empty((b, c, 16, 16), dtype=torch.float32, device=grad_out.device)
+    gws = [torch.empty_like(cv.weight) for cv in stack.convs]
+    gbs = [torch.empty_like(cv.bias) for cv in stack.convs]
+    nl = len(gws)
+    gw_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gws])
+    gb_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbs])
+    tarr = (ctypes.c_double * n)(*t64)
+    _lib.check(lib.odehip_odeint_adjoint_backward(ctypes.byref(desc), ctypes.byref(dg), m, tarr, n, b, _ptr(y_traj),
+                                                  _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr, _ptr(ws), ws.numel(), _stream()))
+    return gz0, gws, gbs
+
+
 class PackedCell:
     """Packed parameters of a ConvGRUCell (conv_gates / conv_can Sequentials), refreshed on parameter change."""
 
