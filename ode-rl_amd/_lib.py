@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libodecgru_hip.so")
+LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
 MAX_LAYERS = 8
 MAX_STAGES = 7

@@ -190,7 +190,7 @@ struct Stamps {
     if (on) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       take(7);
-      unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
+      unsigned long long* o = a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
       o[0] = rt0;
       for (int i = 1; i < 8; ++i) o[i] = cy[i] ? cy[i] - cy[0] : 0;
     }
@@ -209,8 +209,11 @@ __device__ __forceinline__ void mfma4(f32x16& acc, const f32x4& wv, const f32x4&
 // 4 quads x 12 rows (3 pieces) of input], all NCHUNK stages DMA'd at kernel start (8 DMAs per wave
 // per stage: 5 weight pieces (waves 2,3 re-copy piece 17 once) + the 3 pieces of quad `wave`).
 // =================================================================================================
+// The first six dwords (src, weights, cin/4, cout/4) are separate leading arguments so that the hardware preloads them
+// into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count): the first DMA does not wait for an s_load.
 template <int NCHUNK, bool DBG>
-__global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const float* __restrict__ p_src, const float* __restrict__ p_w,
+                                                                  int p_qin, int p_qout, const ConvArgs a) {
   constexpr int TAPS = 9, NP = 3, MC = 2;
   constexpr int W_BYTES = MC * TAPS * 1024, IN_BYTES = 2 * MC * NP * 1024, STAGE = W_BYTES + IN_BYTES;
   constexpr int G = 8;          // DMAs per wave per stage
@@ -229,10 +232,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_resident_kernel(const ConvArgs
   const int r0 = rh * 8;
   const bool dma = !DBG || !(a.debug & 1), mfma = !DBG || !(a.debug & 2);
 
+  (void)p_qout;
   const unsigned tile_w_bytes = (unsigned)NCHUNK * W_BYTES;
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.w_packed + (size_t)ct * tile_w_bytes, tile_w_bytes);
-  const __amdgpu_buffer_rsrc_t rx =
-      make_rsrc((const char*)a.src1 + (size_t)b * a.qin * kQuadBytes, (unsigned)a.qin * kQuadBytes);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)p_w + (size_t)ct * tile_w_bytes, tile_w_bytes);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p_src + (size_t)b * p_qin * kQuadBytes, (unsigned)p_qin * kQuadBytes);
   const int vw = lane * 16;
   int vx[NP];
 #pragma unroll
@@ -507,15 +510,12 @@ __global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------------------------------------- host
 template <typename K>
-static int launch_kernel(K kernel, const ConvArgs& a, size_t lds, hipStream_t stream, bool* attr_set, bool grid2d) {
+static int prepare_kernel(K kernel, size_t lds, bool* attr_set) {
   ODEHIP_REQUIRE(lds <= 160 * 1024, "conv_q4: LDS request %zu exceeds 160 KiB", lds);
   if (!*attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     *attr_set = true;
   }
-  const dim3 grid = grid2d ? dim3((a.qout / 8) * 2, a.batch) : dim3(a.batch * (a.qout / 8) * 2);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, a);
-  ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
 
@@ -523,8 +523,17 @@ template <int NCHUNK>
 static int launch_resident(const ConvArgs& a, hipStream_t stream) {
   static bool attr_set = false, attr_set_dbg = false;
   const size_t lds = (size_t)NCHUNK * 30 * 1024 + 2048;
-  if (a.debug) return launch_kernel(conv3x3_resident_kernel<NCHUNK, true>, a, lds, stream, &attr_set_dbg, true);
-  return launch_kernel(conv3x3_resident_kernel<NCHUNK, false>, a, lds, stream, &attr_set, true);
+  const dim3 grid((a.qout / 8) * 2, a.batch);
+  int rc;
+  if (a.debug) {
+    if ((rc = prepare_kernel(conv3x3_resident_kernel<NCHUNK, true>, lds, &attr_set_dbg)) != ODEHIP_OK) return rc;
+    hipLaunchKernelGGL((conv3x3_resident_kernel<NCHUNK, true>), grid, dim3(256), lds, stream, a.src1, a.w_packed, a.qin, a.qout, a);
+  } else {
+    if ((rc = prepare_kernel(conv3x3_resident_kernel<NCHUNK, false>, lds, &attr_set)) != ODEHIP_OK) return rc;
+    hipLaunchKernelGGL((conv3x3_resident_kernel<NCHUNK, false>), grid, dim3(256), lds, stream, a.src1, a.w_packed, a.qin, a.qout, a);
+  }
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
 }
 
 template <int KS, int MC, int NBUF>
@@ -533,7 +542,12 @@ static int launch_ring(const ConvArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   const int nchunk = a.qin / (2 * MC);
   const int nbuf_alloc = (NBUF < nchunk) ? NBUF : nchunk;
-  return launch_kernel(conv_ring_kernel<KS, MC, NBUF>, a, (size_t)nbuf_alloc * C::STAGE_BYTES + 64, stream, &attr_set, false);
+  const size_t lds = (size_t)nbuf_alloc * C::STAGE_BYTES + 64;
+  int rc = prepare_kernel(conv_ring_kernel<KS, MC, NBUF>, lds, &attr_set);
+  if (rc != ODEHIP_OK) return rc;
+  hipLaunchKernelGGL((conv_ring_kernel<KS, MC, NBUF>), dim3(a.batch * (a.qout / 8) * 2), dim3(256), lds, stream, a);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
 }
 
 int g_debug_flags = 0;
