@@ -58,6 +58,11 @@ size_t odehip_packed_weight_floats(int cout, int cin, int ks);
 int odehip_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
                             int transpose_flip, void* stream);
 
+/* Winograd F(2x2,3x3) form of a 3x3 conv weight (U = G g G^T, 16 values per (cout, cin) pair) in the LDS image of the
+ * Winograd kernel.  Optional: a conv with w_wino == NULL runs the direct kernel. */
+size_t odehip_winograd_weight_floats(int cout, int cin);
+int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cout, int cin, int transpose_flip, void* stream);
+
 int odehip_nchw_to_q4(const float* src_nchw, float* dst_q4, int batch, int channels, void* stream);
 int odehip_q4_to_nchw(const float* src_q4, float* dst_nchw, int batch, int channels, void* stream);
 
@@ -68,6 +73,7 @@ typedef struct odehip_conv_desc {
   const float* src2;      /* Q4 input, channels [cin1, cin); NULL when cin1 == cin (torch.cat) */
   int cin1, cin, cout, ks, batch;
   const float* w_packed;  /* from odehip_pack_conv_weight                                      */
+  const float* w_wino;    /* from odehip_pack_conv_weight_winograd, or NULL (direct kernel)    */
   const float* bias;      /* cout floats or NULL                                               */
   float* dst;             /* Q4 output                                                        */
   int relu;               /* fuse ReLU into the epilogue                                      */
@@ -84,6 +90,7 @@ typedef struct odehip_convstack {
   int ks;                                /* 3                                                       */
   int channels[ODEHIP_MAX_LAYERS + 1];   /* channels[i] -> channels[i+1]                            */
   const float* w_packed[ODEHIP_MAX_LAYERS];
+  const float* w_wino[ODEHIP_MAX_LAYERS];  /* optional Winograd forms (3x3 layers), NULL entries run the direct kernel */
   const float* bias[ODEHIP_MAX_LAYERS];
   int final_tanh;                        /* final_act=True appends Tanh (helpers/utils.py:179-181)  */
 } odehip_convstack;

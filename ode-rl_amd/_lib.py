@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
         ("src1", ctypes.c_void_p), ("src2", ctypes.c_void_p),
         ("cin1", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ks", ctypes.c_int),
         ("batch", ctypes.c_int),
-        ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("w_packed", ctypes.c_void_p), ("w_wino", ctypes.c_void_p), ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("relu", ctypes.c_int),
     ]
 
@@ -33,6 +33,7 @@ class ConvStack(ctypes.Structure):
         ("n_convs", ctypes.c_int), ("ks", ctypes.c_int),
         ("channels", ctypes.c_int * (MAX_LAYERS + 1)),
         ("w_packed", ctypes.c_void_p * MAX_LAYERS),
+        ("w_wino", ctypes.c_void_p * MAX_LAYERS),
         ("bias", ctypes.c_void_p * MAX_LAYERS),
         ("final_tanh", ctypes.c_int),
     ]
@@ -66,6 +67,9 @@ SIGNATURES = {
     "odehip_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "odehip_pack_conv_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_winograd_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "odehip_pack_conv_weight_winograd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_void_p]),
     "odehip_nchw_to_q4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_q4_to_nchw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_conv_q4": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),

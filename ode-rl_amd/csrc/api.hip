@@ -97,6 +97,7 @@ int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, fl
     a.q1 = a.qin = f->channels[l] / 4;
     a.qout = f->channels[l + 1] / 4;
     a.w_packed = f->w_packed[l];
+    a.w_wino = f->w_wino[l];
     a.bias = f->bias[l];
     a.batch = batch;
     a.skip = skip;
@@ -140,6 +141,7 @@ extern "C" int odehip_conv_q4(const odehip_conv_desc* d, void* stream) {
   a.qin = d->cin / 4;
   a.qout = d->cout / 4;
   a.w_packed = d->w_packed;
+  a.w_wino = d->w_wino;
   a.bias = d->bias;
   a.dst = d->dst;
   a.batch = d->batch;

@@ -1,0 +1,130 @@
+// conv_common.h -- device helpers shared by the convolution kernels (conv_q4.hip, conv_wino.hip).
+#pragma once
+#include "odehip_internal.h"
+
+namespace odehip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ODEHIP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int kOobOffset = 0x7fff0000;  // beyond any buffer's num_records -> DMA writes zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  // raw buffer (stride 0), DATA_FORMAT=32 so that the range check is enabled: flags 0x00020000
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, ODEHIP_LDS_PTR(lds), 16, voffset, soffset, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+
+// ---- per-(channel quad Q, pixel P) epilogue: plain / ReLU store, Runge-Kutta stage combine (+ adaptive error
+// partial), ReLU-mask backward, reverse-sweep targets.  `v` is the conv output (bias included) of 4 channels.
+__device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P, f32x4 v, float& esum) {
+  const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
+  if (a.combine == 0) {
+    if (a.relu) {
+      v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+    }
+    *(f32x4*)(a.dst + off) = v;
+    return;
+  }
+  if (a.combine == 2) {
+    const BwdArgs& w = a.bwd;
+    v *= w.sc_c + w.sc_h * (w.h_ptr ? *w.h_ptr : 0.0f);
+    if (w.mask_src) {
+      const f32x4 mk = *(const f32x4*)(w.mask_src + off);
+      v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f;
+      v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+    }
+    *(f32x4*)(a.dst + off) = v;
+    return;
+  }
+  if (a.combine == 3) {
+    const BwdArgs& w = a.bwd;
+    const float hb = w.h_ptr ? *w.h_ptr : 0.0f;
+    for (int t = 0; t < w.n_targets; ++t) {
+      const BwdTarget& T = w.tgt[t];
+      f32x4 o = v * (T.g_c + T.g_h * hb);
+      if (T.srcA) o += *(const f32x4*)(T.srcA + off) * (T.a_c + T.a_h * hb);
+      if (T.srcB) o += *(const f32x4*)(T.srcB + off) * (T.b_c + T.b_h * hb);
+      *(f32x4*)(T.out + off) = o;
+    }
+    return;
+  }
+  const CombineArgs& m = a.cmb;
+  const float h = m.h_ptr ? *m.h_ptr : 1.0f;
+  const f32x4 kc = v * m.k_scale;
+  if (m.k_out) *(f32x4*)(m.k_out + off) = kc;
+  if (m.y) {
+    const f32x4 yv = *(const f32x4*)(m.y + off);
+    f32x4 sa = kc * m.c1[m.n_prev];
+    f32x4 sb = kc * m.c2[m.n_prev];
+    f32x4 se = kc * m.ce[m.n_prev];
+    for (int j = 0; j < m.n_prev; ++j) {
+      const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
+      sa += kp * m.c1[j];
+      sb += kp * m.c2[j];
+      se += kp * m.ce[j];
+    }
+    if (m.out1) *(f32x4*)(m.out1 + off) = yv + sa * h;
+    const f32x4 o2 = yv + sb * h;
+    if (m.out2) *(f32x4*)(m.out2 + off) = o2;
+    if (m.out2_nchw) {
+      float* o = m.out2_nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
+      o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+    }
+    if (m.err_partials) {
+      const f32x4 y1 = *(const f32x4*)(m.err_y1 + off);
+      const f32x4 e = se * h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float tol = m.atol + m.rtol * fmaxf(fabsf(yv[i]), fabsf(y1[i]));
+        const float r = e[i] / tol;
+        esum += r * r;
+      }
+    }
+  }
+}
+
+// diagnostic stamps (debug & 8), shader cycles (s_memtime) relative to the workgroup's start:
+// [1] first DMAs issued, [2] stage 0 landed, [3..6] end of stage 0..3 MFMAs, [7] end; [0] = start in 100 MHz ticks
+struct Stamps {
+  unsigned long long cy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0 = 0;
+  bool on;
+  __device__ __forceinline__ explicit Stamps(const ConvArgs& a, int who = 0) : on((a.debug & 8) && (int)threadIdx.x == who) {}
+  __device__ __forceinline__ void take(int i) {
+    if (on) {
+      cy[i] = __builtin_amdgcn_s_memtime();
+      if (i == 0) rt0 = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+  __device__ __forceinline__ void flush(const ConvArgs& a) {
+    if (on) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      take(7);
+      unsigned long long* o = a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+      o[0] = rt0;
+      for (int i = 1; i < 8; ++i) o[i] = cy[i] ? cy[i] - cy[0] : 0;
+    }
+  }
+};
+
+// one partial of the adaptive error norm per wave (fixed order downstream: no atomics)
+__device__ __forceinline__ void finish_err(const ConvArgs& a, float esum, int wave) {
+  if (a.combine == 1 && a.cmb.err_partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+    if ((threadIdx.x & 63) == 0) a.cmb.err_partials[(blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave] = esum;
+  }
+}
+
+}  // namespace odehip

@@ -26,30 +26,9 @@
 //     streamed in chunks through an NBUF-deep LDS ring with counted s_waitcnt vmcnt(N) + raw s_barrier).
 #include <type_traits>
 
-#include "odehip_internal.h"
+#include "conv_common.h"
 
 namespace odehip {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define ODEHIP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-constexpr int kOobOffset = 0x7fff0000;  // beyond any buffer's num_records -> DMA writes zeros
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  // raw buffer (stride 0), DATA_FORMAT=32 so that the range check is enabled: flags 0x00020000
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, int voffset, int soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, ODEHIP_LDS_PTR(lds), 16, voffset, soffset, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 __device__ __forceinline__ int xcd_block_id() {
   // blocks p and p+8 share an XCD (round-robin dispatch; speed only, never correctness): give each XCD a
@@ -173,29 +152,6 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
     if ((threadIdx.x & 63) == 0) m.err_partials[(blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave] = esum;
   }
 }
-
-// diagnostic stamps (debug & 8), shader cycles (s_memtime) relative to the workgroup's start:
-// [1] first DMAs issued, [2] stage 0 landed, [3..6] end of stage 0..3 MFMAs, [7] end; [0] = start in 100 MHz ticks
-struct Stamps {
-  unsigned long long cy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0 = 0;
-  bool on;
-  __device__ __forceinline__ explicit Stamps(const ConvArgs& a) : on((a.debug & 8) && threadIdx.x == 0) {}
-  __device__ __forceinline__ void take(int i) {
-    if (on) {
-      cy[i] = __builtin_amdgcn_s_memtime();
-      if (i == 0) rt0 = __builtin_amdgcn_s_memrealtime();
-    }
-  }
-  __device__ __forceinline__ void flush(const ConvArgs& a) {
-    if (on) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      take(7);
-      unsigned long long* o = a.dbg + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
-      o[0] = rt0;
-      for (int i = 1; i < 8; ++i) o[i] = cy[i] ? cy[i] - cy[0] : 0;
-    }
-  }
-};
 
 __device__ __forceinline__ void mfma4(f32x16& acc, const f32x4& wv, const f32x4& xv) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc, 0, 0, 0);
@@ -565,6 +521,10 @@ int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
   ODEHIP_REQUIRE((size_t)a.qin * kQuadBytes < (size_t)kOobOffset, "conv_q4: cin too large");
   if (ks == 3) {
     ODEHIP_REQUIRE(a.qin % 4 == 0, "conv_q4: 3x3 needs cin %% 16 == 0 (got %d)", a.qin * 4);
+    if (a.w_wino && a.q1 == a.qin && !(g_debug_flags & 64)) {
+      const int rw = launch_wino(a, stream);
+      if (rw != 1) return rw;
+    }
     if (a.q1 == a.qin && !(g_debug_flags & 16)) {
       switch (a.qin / 4) {
         case 1: return launch_resident<1>(a, stream);

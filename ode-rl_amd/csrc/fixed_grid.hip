@@ -306,6 +306,7 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
       a.q1 = a.qin = f->channels[l + 1] / 4;
       a.qout = f->channels[l] / 4;
       a.w_packed = f_dgrad->w_packed[l];
+      a.w_wino = f_dgrad->w_wino[l];
       a.batch = batch;
       if (l > 0) {
         a.combine = 2;
@@ -470,6 +471,7 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
       a.q1 = a.qin = f->channels[l + 1] / 4;
       a.qout = f->channels[l] / 4;
       a.w_packed = f_dgrad->w_packed[l];
+      a.w_wino = f_dgrad->w_wino[l];
       a.batch = batch;
       if (l > 0) {
         a.combine = 2;

@@ -59,9 +59,56 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   out[idx] = v;
 }
 
+// Winograd F(2x2,3x3) weights U = G g G^T in the LDS image of conv_wino.hip:
+//   out[ct][c][xi][quad][i][s] = U_xi[co = ct*32+i][ci = 16c + 4quad + s],  xi = 4r + col
+__global__ __launch_bounds__(256) void pack_winograd_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
+                                                            int cin, int transpose_flip, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int r = idx;
+  const int s = r & 3; r >>= 2;
+  const int i = r & 31; r >>= 5;
+  const int quad = r & 3; r >>= 2;
+  const int xi = r & 15; r >>= 4;
+  const int nc = cin / 16;
+  const int c = r % nc;
+  const int ct = r / nc;
+  const int co = ct * 32 + i, ci = 16 * c + 4 * quad + s;
+  float g[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      g[ky][kx] = transpose_flip ? w[((size_t)ci * cout + co) * 9 + (2 - ky) * 3 + (2 - kx)] : w[((size_t)co * cin + ci) * 9 + ky * 3 + kx];
+  const int ur = xi >> 2, uc = xi & 3;
+  // row ur of G g (a 3-vector), then its product with column uc of G^T
+  float t[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const float g0 = g[0][kx], g1 = g[1][kx], g2 = g[2][kx];
+    t[kx] = ur == 0 ? g0 : (ur == 1 ? 0.5f * (g0 + g1 + g2) : (ur == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+  }
+  const float uv = uc == 0 ? t[0] : (uc == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (uc == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+  out[idx] = ur == 3 ? -uv : uv;  // conv_wino.hip computes row 3 of B^T d with the opposite sign
+}
+
 }  // namespace odehip
 
 using namespace odehip;
+
+extern "C" size_t odehip_winograd_weight_floats(int cout, int cin) { return (size_t)cout * cin * 16; }
+
+extern "C" int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cout, int cin, int transpose_flip,
+                                                void* stream) {
+  ODEHIP_REQUIRE(w_oihw && w_wino, "pack_conv_weight_winograd: null pointer");
+  ODEHIP_REQUIRE(cout > 0 && cout % 32 == 0, "pack_conv_weight_winograd: cout must be a multiple of 32 (got %d)", cout);
+  ODEHIP_REQUIRE(cin > 0 && cin % 16 == 0, "pack_conv_weight_winograd: cin must be a multiple of 16 (got %d)", cin);
+  const int total = cout * cin * 16;
+  hipLaunchKernelGGL(pack_winograd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, w_wino, cout, cin,
+                     transpose_flip, total);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
 
 extern "C" size_t odehip_packed_weight_floats(int cout, int cin, int ks) {
   return (size_t)cout * cin * ks * ks;

@@ -78,6 +78,7 @@ struct ConvArgs {
   const float* src1;
   const float* src2;
   const float* w_packed;
+  const float* w_wino;   // Winograd-transformed weights (pack_winograd) or null
   const float* bias;
   float* dst;
   int q1;      // channel quads in src1
@@ -94,6 +95,7 @@ struct ConvArgs {
 };
 
 int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
+int launch_wino(const ConvArgs& a, hipStream_t stream);
 extern int g_debug_flags;
 extern unsigned long long* g_debug_buf;
 

@@ -4,6 +4,7 @@ Nothing here computes: every function hands raw device pointers to libodecgru_hi
 current stream.  Tensors must be CUDA fp32; anything else raises (there is no CPU fallback).
 """
 import ctypes
+import os
 
 import torch
 
@@ -73,7 +74,24 @@ def pack_conv_weight(w, transpose_flip=False):
     return out
 
 
-def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False):
+def pack_conv_weight_winograd(w, transpose_flip=False):
+    """(Cout,Cin,3,3) fp32 -> Winograd F(2x2,3x3) image U = G g G^T (16 values per channel pair)."""
+    require_device_tensor(w, "weight")
+    w = w.detach().contiguous()
+    co, ci, k, k2 = w.shape
+    if (k, k2) != (3, 3):
+        raise ValueError("Winograd form exists for 3x3 kernels only")
+    if transpose_flip:
+        co, ci = ci, co
+    out = torch.empty(co * ci * 16, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().odehip_pack_conv_weight_winograd(_ptr(w), _ptr(out), co, ci, int(bool(transpose_flip)), _stream()))
+    return out
+
+
+USE_WINOGRAD = os.environ.get("ODEHIP_NO_WINOGRAD") is None   # 3x3 layers with cin % 16 == 0 run the Winograd kernel (2.25x fewer MFMAs, still exact-fp32 arithmetic)
+
+
+def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False, w_wino=None):
     """One conv layer on Q4 activations (tests / building block)."""
     require_device_tensor(src1, "src1")
     b = src1.shape[0]
@@ -82,6 +100,7 @@ def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False):
     dst = torch.empty((b, cout // 4, 256, 4), dtype=torch.float32, device=src1.device)
     d = _lib.ConvDesc(src1=src1.data_ptr(), src2=src2.data_ptr() if src2 is not None else None, cin1=cin1, cin=cin,
                       cout=cout, ks=ks, batch=b, w_packed=w_packed.data_ptr(),
+                      w_wino=w_wino.data_ptr() if w_wino is not None else None,
                       bias=bias.data_ptr() if bias is not None else None,
                       dst=dst.data_ptr(), relu=int(relu))
     _lib.check(_lib.load().odehip_conv_q4(ctypes.byref(d), _stream()))
@@ -118,6 +137,8 @@ class PackedConvStack:
                                  f"(got {c}); downsize=True dynamics are not supported")
             require_device_tensor(c.weight, "conv weight")
         self._packed = [pack_conv_weight(c.weight) for c in convs]
+        wino_ok = USE_WINOGRAD and ks == 3
+        self._wino = [pack_conv_weight_winograd(c.weight) if wino_ok and c.in_channels % 16 == 0 else None for c in convs]
         self._bias = [c.bias.detach().contiguous() for c in convs]
         d = _lib.ConvStack()
         d.n_convs = len(convs)
@@ -126,6 +147,7 @@ class PackedConvStack:
         for i, c in enumerate(convs):
             d.channels[i + 1] = c.out_channels
             d.w_packed[i] = self._packed[i].data_ptr()
+            d.w_wino[i] = self._wino[i].data_ptr() if self._wino[i] is not None else None
             d.bias[i] = self._bias[i].data_ptr()
         d.final_tanh = int(self.final_tanh)
         self.desc = d
@@ -135,17 +157,20 @@ class PackedConvStack:
 
     def dgrad_desc(self):
         """Stack of the input-gradient convs (weights packed transposed + flipped), built on first use."""
-        self.refresh()
+        d0 = self.refresh()
         if self._dgrad is None:
             packed = [pack_conv_weight(c.weight, transpose_flip=True) for c in self.convs]
+            wino = [pack_conv_weight_winograd(c.weight, transpose_flip=True)
+                    if USE_WINOGRAD and d0.ks == 3 and c.out_channels % 16 == 0 else None for c in self.convs]
             d = _lib.ConvStack()
             d.n_convs, d.ks = self.desc.n_convs, self.desc.ks
             for i in range(len(self.convs) + 1):
                 d.channels[i] = self.desc.channels[i]
             for i, p in enumerate(packed):
                 d.w_packed[i] = p.data_ptr()
+                d.w_wino[i] = wino[i].data_ptr() if wino[i] is not None else None
                 d.bias[i] = self._bias[i].data_ptr()
-            self._dgrad = (d, packed)
+            self._dgrad = (d, packed, wino)
         return self._dgrad[0]
 
 

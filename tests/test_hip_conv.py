@@ -77,3 +77,30 @@ def test_bad_shapes_raise(cuda):
         hip_ops.conv_q4(x, wp, None, 64, 7)  # unsupported kernel size
     with pytest.raises(RuntimeError):
         hip_ops.nchw_to_q4(torch.randn(1, 64, 16, 16))  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("b,cin,cout,relu", [(3, 64, 64, True), (2, 32, 32, False), (1, 16, 64, False), (2, 128, 64, True),
+                                            (5, 64, 128, False)])
+def test_winograd_conv_matches_torch(cuda, b, cin, cout, relu):
+    """Winograd F(2x2,3x3) kernel: still fp32 arithmetic, reassociated; rel-L2 <= 5e-6 vs torch CPU conv2d."""
+    from ode_rl_amd import hip_ops
+    g = torch.Generator().manual_seed(b * 77 + cin + cout)
+    x = torch.randn(b, cin, 16, 16, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    wd = w.to(cuda)
+    out = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(x.to(cuda)), hip_ops.pack_conv_weight(wd), bias.to(cuda), cout, 3,
+                                             relu=relu, w_wino=hip_ops.pack_conv_weight_winograd(wd)))
+    assert rel_l2(out, ref) <= 5e-6
+    if cin % 32 != 0:
+        return
+    # dgrad form (a conv with cin and cout swapped)
+    gy = torch.randn(b, cout, 16, 16, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, padding=1).backward(gy)
+    dg = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(gy.to(cuda)), hip_ops.pack_conv_weight(wd, transpose_flip=True), None,
+                                            cin, 3, w_wino=hip_ops.pack_conv_weight_winograd(wd, transpose_flip=True)))
+    assert rel_l2(dg, xr.grad) <= 5e-6

@@ -13,11 +13,13 @@ from ode_rl_amd import hip_ops, _lib  # noqa: E402
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = hip_ops.nchw_to_q4(torch.randn(B, 64, 16, 16, device=dev))
-w = hip_ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device=dev) / 24)
+wt = torch.randn(64, 64, 3, 3, device=dev) / 24
+w = hip_ops.pack_conv_weight(wt)
+ww = hip_ops.pack_conv_weight_winograd(wt) if hip_ops.USE_WINOGRAD else None
 bias = torch.randn(64, device=dev)
 dst = torch.empty_like(x)
 lib = _lib.load()
-d = _lib.ConvDesc(src1=x.data_ptr(), src2=None, cin1=64, cin=64, cout=64, ks=3, batch=B, w_packed=w.data_ptr(),
+d = _lib.ConvDesc(src1=x.data_ptr(), src2=None, cin1=64, cin=64, cout=64, ks=3, batch=B, w_packed=w.data_ptr(), w_wino=ww.data_ptr() if ww is not None else None,
                   bias=bias.data_ptr(), dst=dst.data_ptr(), relu=1)
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 N = 500
@@ -39,7 +41,7 @@ lib.odehip_set_debug_flags(0)
 # ---- in-kernel stamps (diagnostic build path, flag 8): where does a workgroup spend its time?
 dbg = torch.zeros(B * 4 * 8, dtype=torch.int64, device=dev)
 lib.odehip_set_debug_buffer(ctypes.c_void_p(dbg.data_ptr()))
-lib.odehip_set_debug_flags(8)
+lib.odehip_set_debug_flags(8 | (16 if os.environ.get("STAMP_PRODUCER") else 0))
 lib.odehip_debug_repeat_conv(ctypes.byref(d), 20, stream)
 torch.cuda.synchronize()
 lib.odehip_set_debug_flags(0)
