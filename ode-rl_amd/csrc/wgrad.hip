@@ -85,16 +85,31 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
 
     const char* gbase = gl + i16 * kGPlane + kq * 16;
     const char* abase = al + i16 * kAPlane + kq * 16;  // LDS row 0 = image row -1
+    // K-step ks = 4*y + s covers pixels (y, 4s .. 4s+3).  Fragments of step ks+1 are read (10 ds_read_b128) while the
+    // 36 MFMAs of step ks run: explicit register double buffering.
+    auto load_step = [&](int ks, f32x4& g, f32x4 (&av)[9]) {
+      const int y = ks >> 2, s4 = (ks & 3) * 4;
+      g = *(const f32x4*)(gbase + (y * 16 + s4) * 16);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        av[t] = *(const f32x4*)(abase + ((y + 1 + dy) * 16 + s4 + dx) * 16);
+      }
+    };
+    f32x4 gbuf[2], abuf[2][9];  // ping-pong by K-step parity: no register copies (VALU cycles are MFMA cycles on fp32)
+    load_step(0, gbuf[0], abuf[0]);
     for (int y = 0; y < kHW; ++y) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const f32x4 gv = *(const f32x4*)(gbase + (y * 16 + 4 * s) * 16) * esc;
-        if (wave == 0) bsum += gv;
+        const int ks = y * 4 + s;
+        if (ks + 1 < 64) load_step(ks + 1, gbuf[(s + 1) & 1], abuf[(s + 1) & 1]);
+        const f32x4 gv = gbuf[s & 1] * esc;
+        bsum += gv;  // every wave keeps the bias sums (only wave 0 writes them): no branch in the MFMA stream
         const float ga = wave == 0 ? gv.x : (wave == 1 ? gv.y : (wave == 2 ? gv.z : gv.w));
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int dy = t / 3 - 1, dx = t % 3 - 1;
-          f32x4 av = *(const f32x4*)(abase + ((y + 1 + dy) * 16 + 4 * s + dx) * 16);
+          const int dx = t % 3 - 1;
+          f32x4 av = abuf[s & 1][t];
           if (dx < 0 && s == 0) {  // pixel x-1 of x = 0: only the kq = 0 lanes
             const bool kill = kq == 0;
             av.x = kill ? 0.f : av.x; av.y = kill ? 0.f : av.y; av.z = kill ? 0.f : av.z; av.w = kill ? 0.f : av.w;
@@ -136,20 +151,28 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
   }
 }
 
-// out[i] (+)= sum over slabs, fixed order
+// out[i] = sum over slabs in a fixed order: thread (o, g) adds slabs g, g+4, ... of output o; the 4 partial sums meet in LDS
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int slab_floats,
                                                            float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= slab_floats) return;
-  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // 8 independent chains: the loads overlap; order is fixed
-  for (int k = 0; k < n_slabs; k += 8) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (k + j < n_slabs) p[j] += slabs[(size_t)(k + j) * slab_floats + i];
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;  // independent chains: the loads overlap
+  if (i < slab_floats) {
+    for (int k = g; k < n_slabs; k += 16) {
+      p0 += slabs[(size_t)k * slab_floats + i];
+      if (k + 4 < n_slabs) p1 += slabs[(size_t)(k + 4) * slab_floats + i];
+      if (k + 8 < n_slabs) p2 += slabs[(size_t)(k + 8) * slab_floats + i];
+      if (k + 12 < n_slabs) p3 += slabs[(size_t)(k + 12) * slab_floats + i];
+    }
   }
-  const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-  float* dst = i < 64 * 64 * 9 ? dw + i : db + (i - 64 * 64 * 9);
-  *dst = accumulate ? *dst + s : s;
+  part[g][o] = (p0 + p1) + (p2 + p3);
+  __syncthreads();
+  if (g == 0 && i < slab_floats) {
+    const float s = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    float* dst = i < 64 * 64 * 9 ? dw + i : db + (i - 64 * 64 * 9);
+    *dst = accumulate ? *dst + s : s;
+  }
 }
 
 int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
@@ -161,7 +184,7 @@ int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit
   }
   hipLaunchKernelGGL(wgrad64_kernel, dim3(batch, esplit), dim3(256), kWgradLds, stream, table_dev, n_eval, esplit, slabs);
   const int sf = 64 * 64 * 9 + 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 255) / 256), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, 0);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
