@@ -17,15 +17,15 @@
 //              image slots get an out-of-range offset and the buffer range check writes zeros), then the input
 //              transform V = B^T d B of the next chunk (12 ds_read_b128 + 8 ds_write_b128 + float4 VALU per thread).
 // One s_barrier per chunk hands U_c / V_c to the consumers and the freed buffers back to the producers.
-// LDS: U[2] 64 KiB + raw[2] 24 KiB + V[2] 64 KiB = 152 KiB.
+// LDS: U[2] 64 KiB + raw[2] 32 KiB + V[2] 64 KiB = 160 KiB.
 #include "conv_common.h"
 
 namespace odehip {
 
 constexpr int kWU = 32 * 1024;        // U chunk: 16 xi x [quad 4][co 32][4 ci]
-constexpr int kWRaw = 12 * 1024;      // raw chunk: 4 quads x 3 KiB (192 slots of 16 B; 180 used = 10 rows x 18 cols)
+constexpr int kWRaw = 16 * 1024;      // raw chunk: 4 quads x 4 KiB: 10 rows x 20 slots of 16 B (18 padded cols, de-interleaved)
 constexpr int kWV = 32 * 1024;        // V chunk: 16 xi x [quad 4][tile 32][4 ci]
-constexpr int kWinoLds = 2 * kWU + 2 * kWRaw + 2 * kWV;  // 152 KiB
+constexpr int kWinoLds = 2 * kWU + 2 * kWRaw + 2 * kWV;  // 160 KiB
 
 // a - b on 4 floats as two v_pk_add_f32 with the negate modifier (hipcc emits four v_sub_f32 otherwise; every VALU
 // cycle here is taken from the fp32 MFMAs of the consumer wave on the same SIMD)
@@ -64,14 +64,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
     const unsigned u_tile_bytes = (unsigned)nchunk * kWU;
     const __amdgpu_buffer_rsrc_t ru = make_rsrc((const char*)p_u + (size_t)ct * u_tile_bytes, u_tile_bytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p_src + (size_t)b * p_qin * kQuadBytes, (unsigned)p_qin * kQuadBytes);
-    // raw tile slots: slot s (16 B) = (row s/18, col s%18 - 1) of the padded tile; image row = r0 - 1 + row
-    int vr[3];
+    // Raw tile in LDS: row r (image row r0 - 1 + r) = 20 slots of 16 B: [even padded cols 0,2,..,16 | odd padded cols
+    // 1,3,..,17 | 2 unused]; padded col pc = image col + 1.  A 4x4 patch reads cols 2tx + j: for a fixed j the 8 tiles of a
+    // row hit CONSECUTIVE slots, and the 20-slot row stride puts the 4 tile rows of a ds_read_b128 lane group in
+    // different bank quarters: conflict-free (a plain [row][18 cols] layout is 4-way conflicted on these stride-2 reads).
+    int vr[4];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < 4; ++p) {
       const int s = 64 * p + lane;
-      const int row = s / 18, col = s - row * 18 - 1;
-      const int irow = r0 - 1 + row;
-      vr[p] = (s < 180 && irow >= 0 && irow < kHW && col >= 0 && col < kHW) ? irow * 256 + col * 16 : kOobOffset;
+      const int row = s / 20, w = s - row * 20;
+      const int pc = w < 9 ? 2 * w : 2 * (w - 9) + 1;
+      const int irow = r0 - 1 + row, col = pc - 1;
+      vr[p] = (s < 200 && w < 18 && irow >= 0 && irow < kHW && col >= 0 && col < kHW) ? irow * 256 + col * 16 : kOobOffset;
     }
     const int vw = lane * 16;
     auto issue_u = [&](int c, int buf) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
     };
     auto issue_raw = [&](int c, int buf) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) dma16(rx, Rb + buf * kWRaw + (pw * 3 + p) * 1024, vr[p], (c * 4 + pw) * kQuadBytes);
+      for (int p = 0; p < 4; ++p) dma16(rx, Rb + buf * kWRaw + (pw * 4 + p) * 1024, vr[p], (c * 4 + pw) * kQuadBytes);
     };
     // input transform task: (half th, quad tq, tile tt) -> V rows 2*th, 2*th+1 of B^T d B.  Each producer wave
     // transforms the quad it DMA'd itself (tq = pw), so raw data needs no cross-wave hand-off: its own vmcnt suffices.
@@ -94,8 +98,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
     // sign is folded into the packed U rows of xi = 12..15).  Half 0 loads (p2, p0, p1), half 1 loads (p1, p2, p3): both
     // halves then compute  Ta = d1 - d0,  Tb = d2 + sgn*d0  with sgn = +1 / -1 -- no per-lane selects in the VALU stream.
     const int r_a = th == 0 ? 2 : 1, r_b = th == 0 ? 0 : 2, r_c = th == 0 ? 1 : 3;
-    const int raw_base = tq * 3072 + (2 * tty * 18 + 2 * ttx) * 16;
-    const int off_a = raw_base + r_a * 288, off_b = raw_base + r_b * 288, off_c = raw_base + r_c * 288;
+    const int raw_base = tq * 4096 + (2 * tty * 20 + ttx) * 16;  // + (j&1)*9*16 + (j>>1)*16 per patch column j
+    const int off_a = raw_base + r_a * 320, off_b = raw_base + r_b * 320, off_c = raw_base + r_c * 320;
     const float sgn = th == 0 ? 1.0f : -1.0f;
     const int v_off = tq * 512 + tt * 16;                                  // + xi * 2048
     auto transform = [&](int rbuf, int vbuf) {
@@ -106,9 +110,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
         if (DBG && (a.debug & 512)) {
           d0[j] = d1[j] = d2[j] = f32x4{1.f, 2.f, 3.f, (float)j};
         } else {
-          d0[j] = *(const f32x4*)(r + off_a + j * 16);
-          d1[j] = *(const f32x4*)(r + off_b + j * 16);
-          d2[j] = *(const f32x4*)(r + off_c + j * 16);
+          const int cj = ((j & 1) * 9 + (j >> 1)) * 16;
+          d0[j] = *(const f32x4*)(r + off_a + cj);
+          d1[j] = *(const f32x4*)(r + off_b + cj);
+          d2[j] = *(const f32x4*)(r + off_c + cj);
         }
       }
       f32x4 T[2][4];
@@ -132,15 +137,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
       }
     };
 
-    // DMA issue order per wave: raw_0 (3) | U_0 (8) | raw_1 (3) | then per iteration c: U_{c+1} (8) | raw_{c+2} (3).
+    // DMA issue order per wave: raw_0 (4) | U_0 (8) | raw_1 (4) | then per iteration c: U_{c+1} (8) | raw_{c+2} (4).
     // Counted waits (vmcnt counts this wave's DMAs in issue order) leave the younger ones in flight.
     if (!skip && !dbg_noprod) {
       issue_raw(0, 0);
       issue_u(0, 0);
       if (nchunk > 1) issue_raw(1, 1);
-      if (nchunk > 1) wait_vmcnt<11>(); else wait_vmcnt<8>();  // raw_0 landed (U_0, raw_1 still in flight)
+      if (nchunk > 1) wait_vmcnt<12>(); else wait_vmcnt<8>();  // raw_0 landed (U_0, raw_1 still in flight)
       transform(0, 0);
-      if (nchunk > 1) wait_vmcnt<3>(); else wait_vmcnt<0>();   // U_0 landed
+      if (nchunk > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();   // U_0 landed
     }
     st.take(2);
 #pragma unroll
@@ -150,12 +155,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
         if (!dbg_nodma) issue_u(c + 1, (c + 1) & 1);      // U buffer last read by the MFMAs of chunk c-1
         if (c + 2 < nchunk) {
           if (!dbg_nodma) issue_raw(c + 2, c & 1);        // raw buffer consumed by this wave's transform of chunk c
-          wait_vmcnt<11>();                               // raw_{c+1} landed
+          wait_vmcnt<12>();                               // raw_{c+1} landed
         } else {
           wait_vmcnt<8>();
         }
         if (!dbg_notr) transform((c + 1) & 1, (c + 1) & 1);  // V buffer last read by the MFMAs of chunk c-1
-        if (c + 2 < nchunk) wait_vmcnt<3>(); else wait_vmcnt<0>();  // U_{c+1} landed
+        if (c + 2 < nchunk) wait_vmcnt<4>(); else wait_vmcnt<0>();  // U_{c+1} landed
       }
       if (c < 4) st.take(3 + c);
     }
