@@ -118,7 +118,7 @@ int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_n
  * This is what `loss.backward()` (train_test.py:204) computes through torchdiffeq's fixed-grid ops: the exact gradient
  * of the discrete solver.  f_dgrad->w_packed[l] = odehip_pack_conv_weight(W_l, transpose_flip = 1) in forward layer
  * order (its bias pointers are ignored).  grad_out (T,B,C,16,16) -> grad_z0 (B,C,16,16), grad_w[l] (OIHW), grad_b[l].
- * Deterministic (no float atomics).  Currently 64-channel 3x3 dynamics only. */
+ * Deterministic (no float atomics).  3x3 dynamics with channel counts that are multiples of 64. */
 int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method, const double* t_host,
                                  int n_times, int batch, const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
                                  float* const* grad_b, void* workspace, size_t workspace_bytes, void* stream);
@@ -126,7 +126,7 @@ int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convsta
 /* Adjoint backward: torchdiffeq `odeint_adjoint` semantics (new capability; the reference uses plain autograd).  For
  * i = T-1..1 the augmented state (y, a_y, a_theta) is integrated from t[i] back to t[i-1] with one step of `method`,
  * y is reset to the stored y[i-1], a_y += grad_out[i-1].  y_traj = the forward output (T,B,C,16,16).  Needs no saved
- * activations; workspace size = odehip_odeint_workspace_bytes(..., save_for_backward = 1).  64-channel 3x3 dynamics. */
+ * activations; workspace size = odehip_odeint_workspace_bytes(..., save_for_backward = 1).  3x3 dynamics, channels % 64 == 0. */
 int odehip_odeint_adjoint_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method, const double* t_host,
                                    int n_times, int batch, const float* y_traj_nchw, const float* grad_out_nchw,
                                    float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, void* workspace,

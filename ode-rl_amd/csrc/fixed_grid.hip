@@ -23,8 +23,8 @@ struct WgradPair {
   float scale;
   float pad_[3];
 };
-int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
-                   hipStream_t stream);
+int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                 int cin, hipStream_t stream);
 int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
                      const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
 int check_stack(const odehip_convstack* f);
@@ -46,7 +46,9 @@ struct FixedLayout {
   FixedLayout(const odehip_convstack* f, int batch, int n_times, int method, int save_) {
     T = n_times; B = batch; C = f->channels[0]; S = n_stages(method); NH = f->n_convs - 1; save = save_;
     st = al256((size_t)B * C * kPix * 4);
-    hid = al256((size_t)B * max_hidden(f) * kPix * 4);
+    int cmax = 32;
+    for (int i = 0; i <= f->n_convs; ++i) cmax = f->channels[i] > cmax ? f->channels[i] : cmax;
+    hid = al256((size_t)B * cmax * kPix * 4);   // one slot fits any activation / gradient of the stack
     size_t o = 0;
     auto take = [&](size_t b) { size_t r = o; o += al256(b); return r; };
     off_h = take((size_t)T * 4);
@@ -140,7 +142,7 @@ static int wgrad_all_layers(const odehip_convstack* f, const FixedLayout& L, voi
       }
       hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
     }
-    int rc = launch_wgrad64(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], stream);
+    int rc = launch_wgrad(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream);
     if (rc != ODEHIP_OK) return rc;
   }
   return ODEHIP_OK;
@@ -270,7 +272,7 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(f_dgrad && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace, "odeint_fixed_backward: null pointer");
   for (int l = 0; l <= f->n_convs; ++l)
-    ODEHIP_REQUIRE(f->channels[l] == 64, "odeint_fixed_backward: only 64-channel dynamics are supported (channels[%d] = %d)", l,
+    ODEHIP_REQUIRE(f->channels[l] % 64 == 0, "odeint_fixed_backward: channel counts must be multiples of 64 (channels[%d] = %d)", l,
                    f->channels[l]);
   ODEHIP_REQUIRE(f->ks == 3, "odeint_fixed_backward: 3x3 dynamics only");
   for (int l = 0; l < f->n_convs; ++l)
@@ -291,8 +293,8 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
   if (n_times == 1) {
     ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_z0_nchw, grad_out_nchw, st_b, hipMemcpyDeviceToDevice, stream));
     for (int l = 0; l < NL; ++l) {
-      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)64 * 64 * 9 * 4, stream));
-      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_b[l], 0, 64 * 4, stream));
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)f->channels[l + 1] * f->channels[l] * 9 * 4, stream));
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_b[l], 0, (size_t)f->channels[l + 1] * 4, stream));
     }
     return ODEHIP_OK;
   }
@@ -424,7 +426,7 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
   ODEHIP_REQUIRE(f_dgrad && y_traj_nchw && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace,
                  "odeint_adjoint_backward: null pointer");
   for (int l = 0; l <= f->n_convs; ++l)
-    ODEHIP_REQUIRE(f->channels[l] == 64, "odeint_adjoint_backward: only 64-channel dynamics are supported (channels[%d] = %d)", l,
+    ODEHIP_REQUIRE(f->channels[l] % 64 == 0, "odeint_adjoint_backward: channel counts must be multiples of 64 (channels[%d] = %d)", l,
                    f->channels[l]);
   ODEHIP_REQUIRE(f->ks == 3, "odeint_adjoint_backward: 3x3 dynamics only");
   const FixedLayout L(f, batch, n_times, method, 1);
@@ -448,8 +450,8 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
   if (n_times == 1) {
     ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_z0_nchw, grad_out_nchw, st_b, hipMemcpyDeviceToDevice, stream));
     for (int l = 0; l < NL; ++l) {
-      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)64 * 64 * 9 * 4, stream));
-      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_b[l], 0, 64 * 4, stream));
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)f->channels[l + 1] * f->channels[l] * 9 * 4, stream));
+      ODEHIP_CHECK_HIP(hipMemsetAsync(grad_b[l], 0, (size_t)f->channels[l + 1] * 4, stream));
     }
     return ODEHIP_OK;
   }

@@ -35,8 +35,11 @@ constexpr int kGPlane = 4096 + 16;       // one quad plane of G in LDS (256 px *
 constexpr int kAPlane = 5 * 1024 + 16;   // one quad plane of A in LDS: rows -1..18 (5 DMA pieces), padded
 constexpr int kWgradLds = 16 * kGPlane + 16 * kAPlane;
 
+// One 64(co) x 64(ci) tile of the layer: output channels 4*g_quad0.., input channels 4*a_quad0.. of tensors that
+// have g_quads / a_quads channel quads per sample.
 __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
-                                                         float* __restrict__ slabs) {
+                                                         float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                         int a_quads) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const gl = smem;
   char* const al = smem + 16 * kGPlane;
@@ -64,10 +67,10 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
   for (int e = es; e < n_eval; e += esplit) {
     const WgradPair pr = table[e];
     const float esc = pr.scale;
-    const __amdgpu_buffer_rsrc_t rg =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.g) + (size_t)b * 64 * kPix, 0, 64 * kPix * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.a) + (size_t)b * 64 * kPix, 0, 64 * kPix * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(pr.g) + ((size_t)b * g_quads + g_quad0) * 4 * kPix, 0, 64 * kPix * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(pr.a) + ((size_t)b * a_quads + a_quad0) * 4 * kPix, 0, 64 * kPix * 4, 0x00020000);
     __builtin_amdgcn_s_barrier();  // every wave is done reading the previous evaluation's tiles
     // 16 quads x (4 G pieces + 5 A pieces) = 144 DMAs, 36 per wave: wave w loads quads 4w..4w+3
 #pragma unroll
@@ -152,8 +155,10 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
 }
 
 // out[i] = sum over slabs in a fixed order: thread (o, g) adds slabs g, g+4, ... of output o; the 4 partial sums meet in LDS
+// The 64x64 tile lands at (co0, ci0) of the (cout, cin, 3, 3) gradient; db (only for ci0 == 0) at co0.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int slab_floats,
-                                                           float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+                                                           float* __restrict__ dw, float* __restrict__ db, int cin, int co0,
+                                                           int ci0) {
   __shared__ float part[4][64];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
@@ -170,21 +175,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   if (g == 0 && i < slab_floats) {
     const float s = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
-    float* dst = i < 64 * 64 * 9 ? dw + i : db + (i - 64 * 64 * 9);
-    *dst = accumulate ? *dst + s : s;
+    if (i < 64 * 64 * 9) {
+      const int co = i / (64 * 9), r = i - co * 64 * 9, ci = r / 9, t = r - ci * 9;
+      dw[((size_t)(co0 + co) * cin + ci0 + ci) * 9 + t] = s;
+    } else if (ci0 == 0) {
+      db[co0 + i - 64 * 64 * 9] = s;
+    }
   }
 }
 
-int launch_wgrad64(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
-                   hipStream_t stream) {
+int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                 int cin, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad64_kernel, dim3(batch, esplit), dim3(256), kWgradLds, stream, table_dev, n_eval, esplit, slabs);
   const int sf = 64 * 64 * 9 + 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, 0);
+  for (int co0 = 0; co0 < cout; co0 += 64)
+    for (int ci0 = 0; ci0 < cin; ci0 += 64) {
+      hipLaunchKernelGGL(wgrad64_kernel, dim3(batch, esplit), dim3(256), kWgradLds, stream, table_dev, n_eval, esplit, slabs,
+                         co0 / 4, cout / 4, ci0 / 4, cin / 4);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, cin,
+                         co0, ci0);
+    }
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
