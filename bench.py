@@ -162,7 +162,10 @@ def main():
     wall = float(wall_t.item())
 
     if rank == 0:
-        nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
+        if a.method == "dopri5":
+            nfe_per_step = int(ode_rl_amd.last_stats.get("nfe", 0))
+        else:
+            nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
         n_convs = 5
         launches = nfe_per_step * n_convs * a.steps * (2 if a.train else 1)   # train: + the dgrad conv of every layer
         # ALGORITHMIC work of one 64->64 3x3 layer over the batch (direct-convolution FLOPs); the
@@ -179,9 +182,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
-                                   f"({T - 1} intervals), fixed-step {a.method} (3/8 rule), f = 5x conv3x3(64->64)+ReLU, "
+                                   f"({T - 1} intervals), " + ("adaptive dopri5 rtol 1e-4 atol 1e-5 (DiffEqSolver defaults)" if a.method == "dopri5"
+                                                                else f"fixed-step {a.method} (3/8 rule)") + ", f = 5x conv3x3(64->64)+ReLU, "
                                    + ("forward + backward (discretise-then-optimise)" if a.train else "forward only (BASELINE configs[1])"),
-                       "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}"},
+                       "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}",
+                       "nfe": nfe_per_step},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": profiled_traffic() if a.batch == 64 else None,
