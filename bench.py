@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--frames", type=int, default=10, help="output time points (10 -> 9 intervals)")
     p.add_argument("--method", default="rk4")
     p.add_argument("--train", action="store_true", help="time forward + backward (gradients w.r.t. z0 and all weights)")
+    p.add_argument("--adjoint", action="store_true", help="--train through odeint_adjoint (always the case for dopri5)")
+    p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
+    p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     return p.parse_args()
@@ -114,6 +117,10 @@ def main():
     state = {k: v.detach().clone() for k, v in f.state_dict().items()}
     f = f.to(dev)
     solver = ode_rl_amd.DiffEqSolver(f, a.method, device=dev)
+    if a.rtol is not None:
+        solver.odeint_rtol = a.rtol
+    if a.atol is not None:
+        solver.odeint_atol = a.atol
     g = torch.Generator().manual_seed(1234 + rank)
     z0_cpu = torch.randn(a.batch, 64, 16, 16, generator=g) * 0.5
     z0 = z0_cpu.to(dev)
@@ -135,7 +142,11 @@ def main():
                 return solver(z0, t)
         zz = z0.detach().requires_grad_(True)
         f.zero_grad(set_to_none=False)
-        o = solver(zz, t)
+        if a.adjoint or a.method == "dopri5":
+            o = ode_rl_amd.odeint_adjoint(f, zz, t, rtol=solver.odeint_rtol, atol=solver.odeint_atol, method=a.method,
+                                          adjoint_options={"norm": "seminorm"} if a.method == "dopri5" else None)
+        else:
+            o = solver(zz, t)
         o.backward(gout)
         if dist is not None:   # the ONE collective of a training step: flattened-bucket all-reduce of the gradients
             from ode_rl_amd.dist import allreduce_gradients
@@ -164,10 +175,13 @@ def main():
     if rank == 0:
         if a.method == "dopri5":
             nfe_per_step = int(ode_rl_amd.last_stats.get("nfe", 0))
+            adj = dict(ode_rl_amd.last_adjoint_stats) if a.train else None
         else:
             nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
         n_convs = 5
         launches = nfe_per_step * n_convs * a.steps * (2 if a.train else 1)   # train: + the dgrad conv of every layer
+        if a.method == "dopri5" and a.train:  # adaptive adjoint: each augmented evaluation = forward + dgrad convs
+            launches = (nfe_per_step + 2 * adj.get("nfe", 0)) * n_convs * a.steps
         # ALGORITHMIC work of one 64->64 3x3 layer over the batch (direct-convolution FLOPs); the
         # Winograd kernel executes 2.25x fewer MFMA FLOPs for it, so `frac` is algorithmic throughput over the MFMA peak
         flop_per_launch = conv_flops([64, 64], a.batch)
@@ -182,11 +196,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
-                                   f"({T - 1} intervals), " + ("adaptive dopri5 rtol 1e-4 atol 1e-5 (DiffEqSolver defaults)" if a.method == "dopri5"
+                                   f"({T - 1} intervals), " + (f"adaptive dopri5 rtol {solver.odeint_rtol:g} atol {solver.odeint_atol:g}" if a.method == "dopri5"
                                                                 else f"fixed-step {a.method} (3/8 rule)") + ", f = 5x conv3x3(64->64)+ReLU, "
-                                   + ("forward + backward (discretise-then-optimise)" if a.train else "forward only (BASELINE configs[1])"),
+                                   + (("forward + adjoint backward (seminorm)" if (a.adjoint or a.method == "dopri5") else
+                                       "forward + backward (discretise-then-optimise)") if a.train else "forward only (BASELINE configs[1])"),
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}",
-                       "nfe": nfe_per_step},
+                       "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": profiled_traffic() if a.batch == 64 else None,

@@ -52,16 +52,60 @@ class _AdjointOdeint(torch.autograd.Function):
         return (gz0, None, None, None) + tuple(grads)
 
 
-def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_params=None):
-    """`torchdiffeq.odeint_adjoint(func, y0, t, rtol=, atol=, method=)` for the fixed-grid methods."""
+class _AdjointDopri5(torch.autograd.Function):
+    """odeint_adjoint with method="dopri5": adaptive forward (csrc/dopri5.hip), adaptive augmented backward
+    (csrc/adjoint_dopri5.hip) under the seminorm."""
+
+    @staticmethod
+    def forward(ctx, y0, t_host, cfg, stack, *params):
+        out, stats = hip_ops.odeint_dopri5(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"],
+                                           first_step=cfg["first_step"], max_steps=cfg["max_num_steps"])
+        from .odeint import last_stats
+        last_stats.clear()
+        last_stats.update(stats)
+        ctx.stack, ctx.t_host, ctx.cfg = stack, t_host, cfg
+        ctx.versions = tuple(p._version for p in params)
+        ctx.params = params
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
+        (y_traj,) = ctx.saved_tensors
+        cfg = ctx.cfg
+        stats = {}
+        gz0, gws, gbs = hip_ops.odeint_adjoint_dopri5_backward(ctx.stack, ctx.t_host, y_traj, grad_out, cfg["adjoint_rtol"],
+                                                               cfg["adjoint_atol"], max_accept=cfg["max_accept"], stats=stats)
+        last_adjoint_stats.clear()
+        last_adjoint_stats.update(stats)
+        grads = []
+        for gw, gb in zip(gws, gbs):
+            grads += [gw, gb]
+        return (gz0, None, None, None) + tuple(grads)
+
+
+last_adjoint_stats = {}
+
+
+def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_rtol=None, adjoint_atol=None,
+                   adjoint_method=None, adjoint_options=None, adjoint_params=None):
+    """`torchdiffeq.odeint_adjoint(func, y0, t, rtol=, atol=, method=, adjoint_options=)`.
+
+    Fixed-grid methods: one backward step of the same method per interval.  dopri5: adaptive backward solve; only the
+    `adjoint_options={"norm": "seminorm"}` step control is implemented (the parameter adjoint does not steer the step
+    size -- torchdiffeq's recommended setting), so it has to be asked for explicitly; `max_accept` in adjoint_options
+    bounds the accepted backward steps whose activations are kept for the parameter gradients."""
     from .odeint import FIXED_GRID, _check_monotone, _host_times, conv_stack_of, odeint
     if method is None:
         method = "dopri5"
+    if method not in FIXED_GRID and method != "dopri5":
+        raise ValueError('Invalid method "{}". Must be one of euler, midpoint, rk4, dopri5'.format(method))
+    if adjoint_method is not None and adjoint_method != method:
+        raise NotImplementedError("odeint_adjoint(HIP): adjoint_method must equal method")
     if not torch.is_grad_enabled() or not (y0.requires_grad or any(p.requires_grad for p in func.parameters())):
         return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
-    if method not in FIXED_GRID:
-        raise NotImplementedError("odeint_adjoint(HIP): the adaptive (dopri5) adjoint is not implemented yet; "
-                                  "fixed-grid methods (euler, midpoint, rk4) are")
     hip_ops.require_device_tensor(y0, "y0")
     th = _host_times(t)
     _check_monotone(th)
@@ -71,7 +115,24 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     params = []
     for c in stack.convs:
         params += [c.weight, c.bias]
-    return _AdjointOdeint.apply(y0, th, method, stack, *params)
+    if method in FIXED_GRID:
+        return _AdjointOdeint.apply(y0, th, method, stack, *params)
+    adjoint_options = dict(adjoint_options or {})
+    if adjoint_options.get("norm") != "seminorm":
+        raise NotImplementedError('odeint_adjoint(HIP, dopri5): pass adjoint_options={"norm": "seminorm"}; the default mixed '
+                                  "norm (parameter adjoint steering the step size) is not implemented")
+    unknown = set(adjoint_options) - {"norm", "max_accept"}
+    if unknown:
+        raise ValueError(f"odeint_adjoint(HIP): unsupported adjoint_options {sorted(unknown)}")
+    options = options or {}
+    unknown = set(options) - {"first_step", "max_num_steps"}
+    if unknown:
+        raise ValueError(f"odeint_adjoint(HIP): unsupported dopri5 options {sorted(unknown)}")
+    cfg = dict(rtol=float(rtol), atol=float(atol), first_step=float(options.get("first_step") or 0.0),
+               max_num_steps=int(options.get("max_num_steps") or 0),
+               adjoint_rtol=float(rtol if adjoint_rtol is None else adjoint_rtol),
+               adjoint_atol=float(atol if adjoint_atol is None else adjoint_atol), max_accept=adjoint_options.get("max_accept"))
+    return _AdjointDopri5.apply(y0, th, cfg, stack, *params)
 
 
 def odeint_with_grad(func, y0, t, rtol, atol, method, options=None):

@@ -283,6 +283,39 @@ def odeint_adjoint_backward(stack, method, t, y_traj, grad_out):
     return gz0, gws, gbs
 
 
+def odeint_adjoint_dopri5_backward(stack, t, y_traj, grad_out, rtol, atol, max_accept=None, stats=None):
+    """torchdiffeq odeint_adjoint backward with method="dopri5" and the seminorm: (grad_z0, [grad_w...], [grad_b...]).
+    `stats`, if a dict, receives nfe / n_accept / n_reject of the backward solve."""
+    require_device_tensor(grad_out, "grad_out")
+    require_device_tensor(y_traj, "y_traj")
+    desc = stack.refresh()
+    dg = stack.dgrad_desc()
+    grad_out, y_traj = grad_out.contiguous(), y_traj.contiguous()
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n, b, c = len(t64), y_traj.shape[1], desc.channels[0]
+    lib = _lib.load()
+    if max_accept is None:  # every accepted step keeps its activations: default to what fits in 32 GiB, at most 256 steps
+        per_step = (lib.odehip_adjoint_dopri5_workspace_bytes(ctypes.byref(desc), b, n, 2)
+                    - lib.odehip_adjoint_dopri5_workspace_bytes(ctypes.byref(desc), b, n, 1))
+        max_accept = int(max(4 * n, min(256, (32 << 30) // max(per_step, 1))))
+    nbytes = lib.odehip_adjoint_dopri5_workspace_bytes(ctypes.byref(desc), b, n, int(max_accept))
+    ws = workspace(("adjoint_dopri5", b, n, int(max_accept), tuple(desc.channels)), nbytes, grad_out.device)
+    gz0 = torch.empty((b, c, 16, 16), dtype=torch.float32, device=grad_out.device)
+    gws = [torch.empty_like(cv.weight) for cv in stack.convs]
+    gbs = [torch.empty_like(cv.bias) for cv in stack.convs]
+    nl = len(gws)
+    gw_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gws])
+    gb_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbs])
+    tarr = (ctypes.c_double * n)(*t64)
+    st = (ctypes.c_int * 3)()
+    _lib.check(lib.odehip_odeint_adjoint_dopri5_backward(ctypes.byref(desc), ctypes.byref(dg), tarr, n, b, float(rtol),
+                                                         float(atol), _ptr(y_traj), _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr,
+                                                         int(max_accept), st, _ptr(ws), ws.numel(), _stream()))
+    if stats is not None:
+        stats.update(nfe=int(st[0]), n_accept=int(st[1]), n_reject=int(st[2]))
+    return gz0, gws, gbs
+
+
 class PackedCell:
     """Packed parameters of a ConvGRUCell (conv_gates / conv_can Sequentials), refreshed on parameter change."""
 

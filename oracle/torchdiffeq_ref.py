@@ -289,7 +289,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, stats=N
 
 # --------------------------------------------------------------------------- adjoint
 def odeint_adjoint(func, y0, t, params, grad_out, rtol=1e-7, atol=1e-9, method=None,
-                   stats=None):
+                   stats=None, adjoint_norm="mixed"):
     """torchdiffeq/_impl/adjoint.py semantics, returned functionally.
 
     Forward under no_grad, then the augmented system (y, a_y, a_theta) is integrated
@@ -297,7 +297,9 @@ def odeint_adjoint(func, y0, t, params, grad_out, rtol=1e-7, atol=1e-9, method=N
     from the stored trajectory inside an interval but restarts from `ys[i-1]` at each
     output time; `a_y += grad_out[i-1]` there.  For adaptive methods the error norm of the
     tuple state is the max over per-tensor RMS norms (mixed norm of torchdiffeq 0.2.1), which
-    here is realised by integrating the flat state with that norm.
+    here is realised by integrating the flat state with that norm.  adjoint_norm="seminorm"
+    (adjoint_options={"norm": "seminorm"}, adjoint.py handle_adjoint_norm_) leaves the parameter
+    block out of the error norm: max(rms(y), rms(a_y)).
 
     Returns (ys, grad_y0, [grad_theta...]).
     """
@@ -323,7 +325,9 @@ def odeint_adjoint(func, y0, t, params, grad_out, rtol=1e-7, atol=1e-9, method=N
 
     a_y = grad_out[-1].clone()
     a_p = torch.zeros(sum(sizes), dtype=y0.dtype)
-    norm_chunks = [n_y, n_y] + sizes
+    if adjoint_norm not in ("mixed", "seminorm"):
+        raise ValueError("adjoint_norm must be 'mixed' or 'seminorm'")
+    norm_chunks = [n_y, n_y] + (sizes if adjoint_norm == "mixed" else [])
 
     def mixed_norm(x):
         out, off = None, 0
