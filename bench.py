@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--frames", type=int, default=10, help="output time points (10 -> 9 intervals)")
     p.add_argument("--method", default="rk4")
     p.add_argument("--train", action="store_true", help="time forward + backward (gradients w.r.t. z0 and all weights)")
-    p.add_argument("--adjoint", action="store_true", help="--train through odeint_adjoint (always the case for dopri5)")
+    p.add_argument("--adjoint", action="store_true", help="--train through odeint_adjoint (dopri5: seminorm) instead of backward through the solver")
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +142,7 @@ def main():
                 return solver(z0, t)
         zz = z0.detach().requires_grad_(True)
         f.zero_grad(set_to_none=False)
-        if a.adjoint or a.method == "dopri5":
+        if a.adjoint:
             o = ode_rl_amd.odeint_adjoint(f, zz, t, rtol=solver.odeint_rtol, atol=solver.odeint_atol, method=a.method,
                                           adjoint_options={"norm": "seminorm"} if a.method == "dopri5" else None)
         else:
@@ -175,13 +175,16 @@ def main():
     if rank == 0:
         if a.method == "dopri5":
             nfe_per_step = int(ode_rl_amd.last_stats.get("nfe", 0))
-            adj = dict(ode_rl_amd.last_adjoint_stats) if a.train else None
+            adj = dict(ode_rl_amd.last_adjoint_stats) if (a.train and a.adjoint) else None
         else:
             nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
         n_convs = 5
         launches = nfe_per_step * n_convs * a.steps * (2 if a.train else 1)   # train: + the dgrad conv of every layer
-        if a.method == "dopri5" and a.train:  # adaptive adjoint: each augmented evaluation = forward + dgrad convs
+        if a.method == "dopri5" and a.train and a.adjoint:  # adaptive adjoint: each augmented evaluation = forward + dgrad convs
             launches = (nfe_per_step + 2 * adj.get("nfe", 0)) * n_convs * a.steps
+        elif a.method == "dopri5" and a.train:  # forward + re-integration of the accepted steps + their dgrad chains
+            acc = int(ode_rl_amd.last_stats.get("n_accept", 0))
+            launches = (nfe_per_step + 2 * (6 * acc + 1)) * n_convs * a.steps
         # ALGORITHMIC work of one 64->64 3x3 layer over the batch (direct-convolution FLOPs); the
         # Winograd kernel executes 2.25x fewer MFMA FLOPs for it, so `frac` is algorithmic throughput over the MFMA peak
         flop_per_launch = conv_flops([64, 64], a.batch)
@@ -198,10 +201,11 @@ def main():
             "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
                                    f"({T - 1} intervals), " + (f"adaptive dopri5 rtol {solver.odeint_rtol:g} atol {solver.odeint_atol:g}" if a.method == "dopri5"
                                                                 else f"fixed-step {a.method} (3/8 rule)") + ", f = 5x conv3x3(64->64)+ReLU, "
-                                   + (("forward + adjoint backward (seminorm)" if (a.adjoint or a.method == "dopri5") else
+                                   + (("forward + adjoint backward" + (" (seminorm)" if a.method == "dopri5" else "") if a.adjoint else
                                        "forward + backward (discretise-then-optimise)") if a.train else "forward only (BASELINE configs[1])"),
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}",
-                       "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None},
+                       "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None,
+                       "n_accept": int(ode_rl_amd.last_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": profiled_traffic() if a.batch == 64 else None,

@@ -192,10 +192,25 @@ size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n
  * mailbox; it does not synchronise the stream otherwise).  stats_host[4] (may be NULL) = {nfe, n_accept, n_reject,
  * attempts enqueued}.  first_step > 0 is torchdiffeq's options={'first_step': dt} (skips the initial-step heuristic);
  * max_steps <= 0 means unlimited (torchdiffeq max_num_steps = 2^31-1).
+ * accepted_host (may be NULL): receives (t0, dt) of the accepted steps, in order, at most accepted_cap pairs -- the
+ * input of odehip_odeint_dopri5_backward (stats_host[1] > accepted_cap means the log was cut).
  * Errors: ODEHIP_ENOTCONV (dt underflow / max_steps), ODEHIP_ENAN (non-finite error ratio). */
 int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
                          float rtol, float atol, double first_step, int max_steps, int negate, float* out_nchw,
-                         int* stats_host, void* workspace, size_t workspace_bytes, void* stream);
+                         int* stats_host, double* accepted_host, int accepted_cap, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* `loss.backward()` through odeint(method="dopri5") -- the reference's default training path (configs.yaml:79,
+ * modules/DiffEqSolver.py:9, train_test.py:204): the gradient of the arithmetic of the accepted steps (what autograd
+ * through torchdiffeq differentiates; step sizes are constants, as under torchdiffeq's no_grad step-size update).
+ * Re-integrates the `n_steps` accepted steps of the forward call from z0 keeping activations (n_steps * ~3.5 state-sized
+ * tensors per conv layer), walks them backwards, one weight-gradient launch per layer at the end.  Enqueue-only apart
+ * from one synchronisation per layer for the wgrad table.  3x3 dynamics, channels % 64 == 0, increasing t. */
+size_t odehip_dopri5_backward_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int n_steps);
+int odehip_odeint_dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host, int n_times,
+                                  int batch, const double* accepted_host, int n_steps, const float* z0_nchw,
+                                  const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w, float* const* grad_b,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

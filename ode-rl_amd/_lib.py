@@ -115,8 +115,17 @@ SIGNATURES = {
     "odehip_dopri5_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_int]),
     "odehip_odeint_dopri5": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_double, ctypes.c_int,
-                                            ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p]),
+    "odehip_dopri5_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_int,
+                                                                 ctypes.c_int]),
+    "odehip_odeint_dopri5_backward": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.POINTER(ConvStack),
+                                                     ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                                     ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p,
+                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                                     ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t,
+                                                     ctypes.c_void_p]),
 }
 
 

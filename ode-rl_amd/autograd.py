@@ -28,6 +28,38 @@ class _FixedGridOdeint(torch.autograd.Function):
         return (gz0, None, None, None) + tuple(grads)
 
 
+class _Dopri5Odeint(torch.autograd.Function):
+    """odeint(method="dopri5") under autograd: the gradient of the accepted steps (csrc/dopri5_backward.hip)."""
+
+    @staticmethod
+    def forward(ctx, y0, t_host, cfg, stack, *params):
+        y0d = y0.detach()
+        out, stats = hip_ops.odeint_dopri5(stack, y0d, t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
+                                           max_steps=cfg["max_num_steps"])
+        from .odeint import last_stats
+        last_stats.clear()
+        last_stats.update(stats)
+        if stats["n_accept"] > len(stats["accepted"]):
+            raise RuntimeError(f"odeint(HIP, dopri5): {stats['n_accept']} accepted steps exceed the {hip_ops.LOG_CAP} "
+                               "the backward pass can re-integrate")
+        ctx.stack, ctx.t_host, ctx.accepted = stack, t_host, stats["accepted"]
+        ctx.versions = tuple(p._version for p in params)
+        ctx.params = params
+        ctx.save_for_backward(y0d)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
+        (y0,) = ctx.saved_tensors
+        gz0, gws, gbs = hip_ops.odeint_dopri5_backward(ctx.stack, ctx.t_host, ctx.accepted, y0, grad_out)
+        grads = []
+        for gw, gb in zip(gws, gbs):
+            grads += [gw, gb]
+        return (gz0, None, None, None) + tuple(grads)
+
+
 class _AdjointOdeint(torch.autograd.Function):
     """torchdiffeq.odeint_adjoint: forward without a graph, backward by integrating the adjoint ODE backwards."""
 
@@ -141,10 +173,16 @@ def odeint_with_grad(func, y0, t, rtol, atol, method, options=None):
     _check_monotone(th)
     if len(th) > 1 and bool(th[0] > th[1]):
         raise NotImplementedError("odeint(HIP): reversed-time integration is not implemented yet")
-    if method not in FIXED_GRID:
-        raise NotImplementedError("odeint(HIP): backward through dopri5 is not implemented yet (use a fixed-grid method)")
     stack = conv_stack_of(func)
     params = []
     for c in stack.convs:
         params += [c.weight, c.bias]
-    return _FixedGridOdeint.apply(y0, th, method, stack, *params)
+    if method in FIXED_GRID:
+        return _FixedGridOdeint.apply(y0, th, method, stack, *params)
+    options = options or {}
+    unknown = set(options) - {"first_step", "max_num_steps"}
+    if unknown:
+        raise ValueError(f"odeint(HIP): unsupported dopri5 options {sorted(unknown)}")
+    cfg = dict(rtol=float(rtol), atol=float(atol), first_step=float(options.get("first_step") or 0.0),
+               max_num_steps=int(options.get("max_num_steps") or 0))
+    return _Dopri5Odeint.apply(y0, th, cfg, stack, *params)

@@ -52,8 +52,12 @@ struct DopriState {
   int max_steps;
 };
 
+constexpr int kMailboxBytes = 65536;
+constexpr int kLogCap = (kMailboxBytes - 64) / 16;
 struct Mailbox {  // pinned host memory, written by the controller with system-scope stores
   volatile int steps_done, done, status, n_accept, n_reject, nfe;
+  int pad_[10];
+  volatile double log[kLogCap][2];  // (t0, dt) of every accepted step, in order (what a backward pass re-integrates)
 };
 
 // ---- deterministic block reduction of `n` floats (fixed order), result valid in thread 0
@@ -177,6 +181,10 @@ __global__ __launch_bounds__(256) void controller_kernel(DopriState* st, const f
   if (!finite) status = ODEHIP_ENAN;  // torchdiffeq asserts isfinite(y) at the next step; a NaN ratio never accepts
   if (accept) {
     const double t1n = st->t1 + dt;
+    if (st->n_accept < kLogCap) {
+      mb->log[st->n_accept][0] = st->t1;
+      mb->log[st->n_accept][1] = dt;
+    }
     st->t0 = st->t1;
     st->t1 = t1n;
     st->n_accept += 1;
@@ -335,7 +343,8 @@ extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int b
 
 extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
                                     int batch, float rtol, float atol, double first_step, int max_steps, int negate,
-                                    float* out_nchw, int* stats_host, void* workspace, size_t workspace_bytes, void* stream_) {
+                                    float* out_nchw, int* stats_host, double* accepted_host, int accepted_cap, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(z0_nchw && t_host && out_nchw && workspace, "odeint_dopri5: null pointer");
@@ -355,8 +364,8 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   const int red_grid = 256;
 
   if (!g_mailbox) {
-    // 4 KiB of pinned, coherent host memory for the controller's progress word: the only allocation this library makes
-    ODEHIP_CHECK_HIP(hipHostMalloc((void**)&g_mailbox, 4096, hipHostMallocCoherent));
+    // 64 KiB of pinned, coherent host memory for the controller's progress word and its log of accepted steps
+    ODEHIP_CHECK_HIP(hipHostMalloc((void**)&g_mailbox, kMailboxBytes, hipHostMallocCoherent));
   }
   memset((void*)g_mailbox, 0, sizeof(Mailbox));
 
@@ -493,6 +502,14 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
     stats_host[1] = g_mailbox->n_accept;
     stats_host[2] = g_mailbox->n_reject;
     stats_host[3] = enq;
+  }
+  if (accepted_host) {  // (t0, dt) pairs; the caller sees from stats_host[1] > accepted_cap that the log is incomplete
+    int n = g_mailbox->n_accept < kLogCap ? g_mailbox->n_accept : kLogCap;
+    if (n > accepted_cap) n = accepted_cap;
+    for (int i = 0; i < n; ++i) {
+      accepted_host[2 * i] = g_mailbox->log[i][0];
+      accepted_host[2 * i + 1] = g_mailbox->log[i][1];
+    }
   }
   if (g_mailbox->status == ODEHIP_ENAN) {
     set_error("odeint_dopri5: non-finite error ratio (non-finite values in state `y`)");

@@ -237,8 +237,11 @@ def odeint_fixed_backward(stack, method, t, batch, grad_out, ws):
     return gz0, gws, gbs
 
 
+LOG_CAP = 2048   # accepted steps the forward reports back (the backward pass re-integrates them)
+
+
 def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=False):
-    """Adaptive dopri5 trajectory; returns ((T,B,C,16,16), stats dict)."""
+    """Adaptive dopri5 trajectory; returns ((T,B,C,16,16), stats dict).  stats["accepted"] = [(t0, dt), ...]."""
     require_device_tensor(z0, "y0")
     desc = stack.refresh()
     z0 = z0.contiguous()
@@ -253,9 +256,39 @@ def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=
     out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
     tarr = (ctypes.c_double * n)(*t64)
     stats = (ctypes.c_int * 4)()
+    log = (ctypes.c_double * (2 * LOG_CAP))()
     _lib.check(lib.odehip_odeint_dopri5(ctypes.byref(desc), _ptr(z0), tarr, n, b, float(rtol), float(atol), float(first_step or 0.0), int(max_steps),
-                                        int(bool(negate)), _ptr(out), stats, _ptr(ws), ws.numel(), _stream()))
-    return out, {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3]}
+                                        int(bool(negate)), _ptr(out), stats, log, LOG_CAP, _ptr(ws), ws.numel(), _stream()))
+    k = min(int(stats[1]), LOG_CAP)
+    return out, {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3],
+                 "accepted": [(log[2 * i], log[2 * i + 1]) for i in range(k)]}
+
+
+def odeint_dopri5_backward(stack, t, accepted, z0, grad_out):
+    """Gradient of the accepted dopri5 steps (what autograd through torchdiffeq computes): (grad_z0, [grad_w], [grad_b])."""
+    require_device_tensor(grad_out, "grad_out")
+    require_device_tensor(z0, "y0")
+    desc = stack.refresh()
+    dg = stack.dgrad_desc()
+    grad_out, z0 = grad_out.contiguous(), z0.contiguous()
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n, b, c = len(t64), z0.shape[0], desc.channels[0]
+    ns = len(accepted)
+    lib = _lib.load()
+    nbytes = lib.odehip_dopri5_backward_workspace_bytes(ctypes.byref(desc), b, n, ns)
+    ws = workspace(("dopri5_bwd", b, n, ns, tuple(desc.channels)), nbytes, grad_out.device)
+    gz0 = torch.empty((b, c, 16, 16), dtype=torch.float32, device=grad_out.device)
+    gws = [torch.empty_like(cv.weight) for cv in stack.convs]
+    gbs = [torch.empty_like(cv.bias) for cv in stack.convs]
+    nl = len(gws)
+    gw_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gws])
+    gb_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbs])
+    tarr = (ctypes.c_double * n)(*t64)
+    flat = [v for pair in accepted for v in pair]
+    larr = (ctypes.c_double * max(len(flat), 1))(*flat)
+    _lib.check(lib.odehip_odeint_dopri5_backward(ctypes.byref(desc), ctypes.byref(dg), tarr, n, b, larr, ns, _ptr(z0),
+                                                 _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr, _ptr(ws), ws.numel(), _stream()))
+    return gz0, gws, gbs
 
 
 def odeint_adjoint_backward(stack, method, t, y_traj, grad_out):

@@ -176,7 +176,9 @@ def _error_ratio(err, rtol, atol, y0, y1, norm):
 
 
 def _optimal_step_size(last_step, error_ratio):
-    """torchdiffeq/_impl/rk_common.py:_optimal_step_size (order 5)."""
+    """torchdiffeq/_impl/misc.py:_optimal_step_size (order 5).  Decorated @torch.no_grad() there: the next step size is a
+    constant of the autograd graph (only the very first dt, from _select_initial_step, carries a gradient)."""
+    last_step = last_step.detach()
     if error_ratio == 0:
         return last_step * IFACTOR
     dfactor = 1.0 if error_ratio < 1 else DFACTOR
