@@ -182,6 +182,36 @@ int odehip_odeconvgru_encode(const odehip_encoder* e, const float* inputs_nchw, 
                              float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* ---- training path of the encoder: `loss.backward()` through ODEConvGRUCell.forward (train_test.py:204) ---------------- */
+
+typedef struct odehip_encoder_bwd {
+  odehip_convstack f_dgrad;    /* encoder dynamics with weights packed transpose_flip = 1 (bias pointers ignored)          */
+  const float* w_gates_dx;     /* odehip_pack_conv_weight(conv_gates.0.weight[:, :input],  transpose_flip = 1)              */
+  const float* w_gates_dh;     /* ... conv_gates.0.weight[:, input:]                                                       */
+  const float* w_can_dx;       /* ... conv_can.0.weight[:, :input]                                                         */
+  const float* w_can_dh;       /* ... conv_can.0.weight[:, input:]                                                         */
+  const float* w_head0_t;      /* ... transform_z0.0.weight, transform_z0.2.weight                                         */
+  const float* w_head1_t;
+} odehip_encoder_bwd;
+
+typedef struct odehip_encoder_grads {  /* outputs, each shaped like its parameter (conv weights OIHW) */
+  float* f_w[ODEHIP_MAX_LAYERS];
+  float* f_b[ODEHIP_MAX_LAYERS];
+  float *w_gates, *b_gates, *gn_gates_w, *gn_gates_b, *w_can, *b_can, *gn_can_w, *gn_can_b;
+  float *w_head0, *b_head0, *w_head1, *b_head1;
+} odehip_encoder_grads;
+
+/* Forward that keeps the conv outputs of every frame in `workspace` (which the caller must leave untouched until the
+ * backward call), then the reverse sweep: grad_mean / grad_std (B,out_ch,16,16) -> grad_inputs (T,B,C,16,16) and the
+ * gradient of every parameter of the encoder dynamics, the ConvGRU cell (incl. GroupNorm affine) and the 1x1 head.
+ * Channel counts must be multiples of 64, encoder dynamics 3x3.  Deterministic (no float atomics). */
+size_t odehip_encoder_train_workspace_bytes(const odehip_encoder* e, int n_frames, int batch);
+int odehip_odeconvgru_encode_train(const odehip_encoder* e, const float* inputs_nchw, const double* t_host, int n_frames, int batch,
+                                   float* mean_nchw, float* std_nchw, void* workspace, size_t workspace_bytes, void* stream);
+int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const odehip_encoder_bwd* eb, const double* t_host, int n_frames,
+                                      int batch, const float* grad_mean_nchw, const float* grad_std_nchw, float* grad_inputs_nchw,
+                                      const odehip_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- odeint, adaptive dopri5 (torchdiffeq Dopri5Solver; the reference's default method, configs.yaml:79) ------ */
 
 size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times);

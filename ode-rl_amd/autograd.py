@@ -60,6 +60,32 @@ class _Dopri5Odeint(torch.autograd.Function):
         return (gz0, None, None, None) + tuple(grads)
 
 
+class _EncodeFn(torch.autograd.Function):
+    """ODEConvGRUCell.forward under autograd: csrc/convgru_backward.hip keeps the per-frame conv outputs and sweeps back."""
+
+    @staticmethod
+    def forward(ctx, inputs, timesteps, enc, *params):
+        mean, std, saved = hip_ops.odeconvgru_encode_train(enc, inputs.detach(), timesteps)
+        ctx.enc, ctx.saved = enc, saved
+        ctx.versions = tuple(p._version for p in params)
+        ctx.params = params
+        return mean, std
+
+    @staticmethod
+    def backward(ctx, grad_mean, grad_std):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("an encoder parameter was modified in place between forward and backward")
+        if ctx.saved is None:
+            raise RuntimeError("the encoder's saved activations were already consumed (backward called twice)")
+        gin, grads = hip_ops.odeconvgru_encode_backward(ctx.enc, ctx.saved, grad_mean, grad_std)
+        ctx.saved = None
+        return (gin, None, None) + tuple(grads)
+
+
+def encode_with_grad(enc, inputs, timesteps):
+    return _EncodeFn.apply(inputs, timesteps, enc, *hip_ops.encoder_params(enc))
+
+
 class _AdjointOdeint(torch.autograd.Function):
     """torchdiffeq.odeint_adjoint: forward without a graph, backward by integrating the adjoint ODE backwards."""
 

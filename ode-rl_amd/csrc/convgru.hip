@@ -196,6 +196,22 @@ extern "C" size_t odehip_convgru_cell_workspace_bytes(const odehip_convgru_cell*
   return al256((size_t)batch * c->input * kPix * 4) + 6 * hs;  // x, h, gates_raw(2), z, rh, cand_raw... + h_out
 }
 
+namespace odehip {  // shared with the training path (convgru_backward.hip)
+int cell_step_q4(const odehip_convgru_cell* c, const float* x, const float* h, float* h_out, float* h_out_nchw,
+                 long long nchw_batch_stride, int batch, float* gates_raw, float* z, float* rh, float* cand_raw, hipStream_t stream) {
+  return cell_step(c, x, h, h_out, h_out_nchw, nchw_batch_stride, batch, gates_raw, z, rh, cand_raw, stream);
+}
+int conv_layer_q4(const float* src1, const float* src2, int cin1, int cin, int cout, int ks, const float* wp, const float* bias,
+                  float* dst, int relu, int batch, hipStream_t stream) {
+  return conv_layer(src1, src2, cin1, cin, cout, ks, wp, bias, dst, relu, batch, stream);
+}
+void launch_split_mean_std(const float* head_out, float* mean, float* stdv, int batch, int out_ch, hipStream_t stream) {
+  const int total = batch * (2 * out_ch / 4) * kPix;
+  hipLaunchKernelGGL(split_mean_std_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, head_out, mean, stdv, total, out_ch / 4);
+}
+int check_cell_desc(const odehip_convgru_cell* c) { return check_cell(c); }
+}  // namespace odehip
+
 // x: (B,input,16,16), h: (B,hidden,16,16) NCHW -> h_next NCHW      (ConvGRUCell.forward with seq_len = 1)
 extern "C" int odehip_convgru_cell_forward(const odehip_convgru_cell* c, const float* x_nchw, const float* h_nchw,
                                            float* h_next_nchw, int batch, void* workspace, size_t workspace_bytes,

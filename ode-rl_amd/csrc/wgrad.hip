@@ -184,6 +184,183 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ---- generic tile kernel for the other layer shapes of the encoder (5x5 ConvGRU convs, 1x1 head): same structure, taps
+// (ty, tx) with ty in [TY0, TY0+NTY): a 5x5 layer takes three launches (tap rows 0-1, 2-3, 4) so the accumulators fit.
+template <int KS, int TY0, int NTY>
+__global__ __launch_bounds__(256, 1) void wgrad_tile_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                            float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                            int a_quads) {
+  constexpr int HALO = KS / 2, NT = NTY * KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const gl = smem;
+  char* const al = smem + 16 * kGPlane;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x, es = blockIdx.y;
+  const int i16 = lane & 15, kq = lane >> 4;
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  int va[5];  // piece r covers image rows 4r-HALO .. 4r-HALO+3; out-of-image rows -> zero fill
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int row = 4 * r - HALO + (lane >> 4);
+    va[r] = (row >= 0 && row < kHW) ? row * 256 + (lane & 15) * 16 : 0x7fff0000;
+  }
+  const int vg = lane * 16;
+
+  for (int e = es; e < n_eval; e += esplit) {
+    const WgradPair pr = table[e];
+    const float esc = pr.scale;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(pr.g) + ((size_t)b * g_quads + g_quad0) * 4 * kPix, 0, 64 * kPix * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(pr.a) + ((size_t)b * a_quads + a_quad0) * 4 * kPix, 0, 64 * kPix * 4, 0x00020000);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int q = wave * 4 + qq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, ODEHIP_LDS_PTR(gl + q * kGPlane + r * 1024), 16, vg, q * 4096 + r * 1024, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, ODEHIP_LDS_PTR(al + q * kAPlane + r * 1024), 16, va[r], q * 4096, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const char* gbase = gl + i16 * kGPlane + kq * 16;
+    const char* abase = al + i16 * kAPlane + kq * 16;  // LDS row 0 = image row -HALO
+    auto load_step = [&](int ks, f32x4& g, f32x4 (&av)[NT]) {
+      const int y = ks >> 2, s4 = (ks & 3) * 4;
+      g = *(const f32x4*)(gbase + (y * 16 + s4) * 16);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int dy = TY0 + t / KS - HALO, dx = t % KS - HALO;
+        av[t] = *(const f32x4*)(abase + ((y + HALO + dy) * 16 + s4 + dx) * 16);
+      }
+    };
+    f32x4 gbuf[2], abuf[2][NT];
+    load_step(0, gbuf[0], abuf[0]);
+    for (int y = 0; y < kHW; ++y) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int ks = y * 4 + s;
+        if (ks + 1 < 64) load_step(ks + 1, gbuf[(s + 1) & 1], abuf[(s + 1) & 1]);
+        const f32x4 gv = gbuf[s & 1] * esc;
+        bsum += gv;
+        const float ga = wave == 0 ? gv.x : (wave == 1 ? gv.y : (wave == 2 ? gv.z : gv.w));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int dx = t % KS - HALO;
+          f32x4 av = abuf[s & 1][t];
+          if ((dx < 0 && s == 0) || (dx > 0 && s == 3)) {  // pixel x+dx outside the row: x = 4s + kq
+            const bool kill = (dx < 0) ? (kq + dx < 0) : (kq + dx > 3);
+            av.x = kill ? 0.f : av.x; av.y = kill ? 0.f : av.y; av.z = kill ? 0.f : av.z; av.w = kill ? 0.f : av.w;
+          }
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.x, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.y, acc[t][1], 0, 0, 0);
+          acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.z, acc[t][2], 0, 0, 0);
+          acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, av.w, acc[t][3], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  float* slab = slabs + (size_t)(b * esplit + es) * (64 * 64 * NT + 64);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * (4 * kq + r) + wave;
+        const int ci = 4 * i16 + n;
+        slab[((size_t)co * 64 + ci) * NT + t] = acc[t][n][r];
+      }
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (kq == 0) slab[64 * 64 * NT + 4 * i16 + c] = v;
+    }
+  }
+}
+
+// fixed-order sum of the slabs of one tile launch; taps [t0, t0+nt) of a layer with `taps` taps in all
+__global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int nt, int t0, int taps,
+                                                                float* __restrict__ dw, float* __restrict__ db, int cin, int co0,
+                                                                int ci0, int write_bias) {
+  __shared__ float part[4][64];
+  const int slab_floats = 64 * 64 * nt + 64;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float p = 0.f;
+  if (i < slab_floats)
+    for (int k = g; k < n_slabs; k += 4) p += slabs[(size_t)k * slab_floats + i];
+  part[g][o] = p;
+  __syncthreads();
+  if (g == 0 && i < slab_floats) {
+    const float s = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    if (i < 64 * 64 * nt) {
+      const int co = i / (64 * nt), r = i - co * 64 * nt, ci = r / nt, t = r - ci * nt;
+      dw[((size_t)(co0 + co) * cin + ci0 + ci) * taps + t0 + t] = s;
+    } else if (write_bias) {
+      db[co0 + i - 64 * 64 * nt] = s;
+    }
+  }
+}
+
+template <int KS, int TY0, int NTY>
+static int launch_tile_part(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
+                            int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
+                            hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_tile_kernel<KS, TY0, NTY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+    attr_set = true;
+  }
+  constexpr int NT = NTY * KS;
+  hipLaunchKernelGGL((wgrad_tile_kernel<KS, TY0, NTY>), dim3(batch, esplit), dim3(256), kWgradLds, stream, table_dev, n_eval, esplit,
+                     slabs, g_quad0, g_quads, a_quad0, a_quads);
+  const int sf = 64 * 64 * NT + 64;
+  hipLaunchKernelGGL(wgrad_tile_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, NT, TY0 * KS,
+                     KS * KS, dw, db, cin_total, co0, ci0, (int)(write_bias && TY0 == 0));
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+// One 64 x 64 tile of dW (cout_total, cin_total, ks, ks): output channels co0.. from G tensors with g_quads quads per sample
+// (tile at quad g_quad0), input channels ci0.. of the WEIGHT from A tensors with a_quads quads per sample (tile at a_quad0) --
+// the A tensor may be one half of a concatenated conv input.  slabs: batch*esplit*(64*64*10+64) floats.
+int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
+                      int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
+                      hipStream_t stream) {
+  int rc;
+  if (ks == 1) return launch_tile_part<1, 0, 1>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0,
+                                                a_quads, a_quad0, write_bias, stream);
+  if (ks == 3) return launch_tile_part<3, 0, 3>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0,
+                                                a_quads, a_quad0, write_bias, stream);
+  ODEHIP_REQUIRE(ks == 5, "wgrad: kernel size %d unsupported", ks);
+  rc = launch_tile_part<5, 0, 2>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads, a_quad0,
+                                 write_bias, stream);
+  if (rc != ODEHIP_OK) return rc;
+  rc = launch_tile_part<5, 2, 2>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads, a_quad0,
+                                 write_bias, stream);
+  if (rc != ODEHIP_OK) return rc;
+  return launch_tile_part<5, 4, 1>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads,
+                                   a_quad0, write_bias, stream);
+}
+
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                  int cin, hipStream_t stream) {
   static bool attr_set = false;

@@ -431,6 +431,85 @@ class PackedEncoder:
         return d
 
 
+def encoder_params(enc):
+    """Parameters of the encoder in the order the training path returns their gradients."""
+    cell = enc.packed_cell.cell
+    ps = []
+    for c in enc.f_stack.convs:
+        ps += [c.weight, c.bias]
+    ps += [cell.conv_gates[0].weight, cell.conv_gates[0].bias, cell.conv_gates[1].weight, cell.conv_gates[1].bias,
+           cell.conv_can[0].weight, cell.conv_can[0].bias, cell.conv_can[1].weight, cell.conv_can[1].bias,
+           enc.head[0].weight, enc.head[0].bias, enc.head[2].weight, enc.head[2].bias]
+    return ps
+
+
+def _encoder_bwd_desc(enc):
+    """Transposed + flipped weight images of the input-gradient convs (rebuilt when a parameter changes)."""
+    d = enc.refresh()
+    stamp = enc._stamp
+    cached = getattr(enc, "_bwd", None)
+    if cached is not None and cached[0] is stamp:
+        return cached[1]
+    cell = enc.packed_cell.cell
+    i = d.cell.input
+    wg, wc = cell.conv_gates[0].weight.detach(), cell.conv_can[0].weight.detach()
+    keep = [pack_conv_weight(wg[:, :i], True), pack_conv_weight(wg[:, i:], True), pack_conv_weight(wc[:, :i], True),
+            pack_conv_weight(wc[:, i:], True), pack_conv_weight(enc.head[0].weight, True), pack_conv_weight(enc.head[2].weight, True)]
+    b = _lib.EncoderBwd()
+    b.f_dgrad = enc.f_stack.dgrad_desc()
+    b.w_gates_dx, b.w_gates_dh, b.w_can_dx, b.w_can_dh, b.w_head0_t, b.w_head1_t = (k.data_ptr() for k in keep)
+    enc._bwd = (stamp, b, keep)
+    return b
+
+
+def odeconvgru_encode_train(enc, inputs, timesteps):
+    """Forward of the training path: returns (mean, std, saved) -- `saved` holds the workspace the backward call needs."""
+    require_device_tensor(inputs, "inputs")
+    d = enc.refresh()
+    inputs = inputs.contiguous()
+    t, b, c = inputs.shape[0], inputs.shape[1], inputs.shape[2]
+    if inputs.dim() != 5 or tuple(inputs.shape[3:]) != (16, 16) or c != d.cell.hidden:
+        raise ValueError(f"inputs must be (T,B,{d.cell.hidden},16,16) time-first (got {tuple(inputs.shape)})")
+    t64 = [float(v) for v in timesteps.detach().to("cpu", torch.float64).tolist()]
+    assert t == len(t64), "Sequence length should be same as time_steps"
+    lib = _lib.load()
+    nbytes = lib.odehip_encoder_train_workspace_bytes(ctypes.byref(d), t, b)
+    ws = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=inputs.device)   # owned by this call's graph node
+    mean = torch.empty((b, d.out_ch, 16, 16), dtype=torch.float32, device=inputs.device)
+    std = torch.empty_like(mean)
+    tarr = (ctypes.c_double * t)(*t64)
+    _lib.check(lib.odehip_odeconvgru_encode_train(ctypes.byref(d), _ptr(inputs), tarr, t, b, _ptr(mean), _ptr(std), _ptr(ws),
+                                                  ws.numel(), _stream()))
+    return mean, std, (ws, t64, t, b, c)
+
+
+def odeconvgru_encode_backward(enc, saved, grad_mean, grad_std):
+    """(grad_inputs (T,B,C,16,16), [gradient of every tensor of encoder_params(enc)])."""
+    ws, t64, t, b, c = saved
+    d = enc.refresh()
+    bw = _encoder_bwd_desc(enc)
+    dev = ws.device
+    grad_mean = (torch.zeros((b, d.out_ch, 16, 16), device=dev) if grad_mean is None else grad_mean).contiguous()
+    grad_std = (torch.zeros((b, d.out_ch, 16, 16), device=dev) if grad_std is None else grad_std).contiguous()
+    require_device_tensor(grad_mean, "grad_mean")
+    require_device_tensor(grad_std, "grad_std")
+    params = encoder_params(enc)
+    grads = [torch.empty_like(p) for p in params]
+    g = _lib.EncoderGrads()
+    nl = len(enc.f_stack.convs)
+    for l in range(nl):
+        g.f_w[l] = grads[2 * l].data_ptr()
+        g.f_b[l] = grads[2 * l + 1].data_ptr()
+    (g.w_gates, g.b_gates, g.gn_gates_w, g.gn_gates_b, g.w_can, g.b_can, g.gn_can_w, g.gn_can_b, g.w_head0, g.b_head0, g.w_head1,
+     g.b_head1) = (x.data_ptr() for x in grads[2 * nl:])
+    gin = torch.empty((t, b, c, 16, 16), dtype=torch.float32, device=dev)
+    tarr = (ctypes.c_double * t)(*t64)
+    _lib.check(_lib.load().odehip_odeconvgru_encode_backward(ctypes.byref(d), ctypes.byref(bw), tarr, t, b, _ptr(grad_mean),
+                                                             _ptr(grad_std), _ptr(gin), ctypes.byref(g), _ptr(ws), ws.numel(),
+                                                             _stream()))
+    return gin, grads
+
+
 def odeconvgru_encode(enc, inputs, timesteps, want_latent=False):
     require_device_tensor(inputs, "inputs")
     d = enc.refresh()

@@ -30,7 +30,11 @@ class ODEConvGRUCell(nn.Module):
 
     def forward(self, inputs, timesteps, mask=None):
         """inputs (T,B,C,H,W) time-first -> (mean_z0, std_z0), each (B, z0_dim, H, W); std is |.| (reference :32-37)."""
-        mean, std, _ = hip_ops.odeconvgru_encode(self._packed(), inputs, timesteps)
+        enc = self._packed()
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in hip_ops.encoder_params(enc))):
+            from ..autograd import encode_with_grad
+            return encode_with_grad(enc, inputs, timesteps)
+        mean, std, _ = hip_ops.odeconvgru_encode(enc, inputs, timesteps)
         return mean, std
 
     def run_ode_conv_gru(self, inputs, timesteps, run_backwards=True, mask=None):
@@ -38,5 +42,8 @@ class ODEConvGRUCell(nn.Module):
         device path (it is the only mode the reference ever uses, :33)."""
         if not run_backwards:
             raise NotImplementedError("run_ode_conv_gru(run_backwards=False) is not supported by the HIP path")
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("run_ode_conv_gru(HIP): latent_ys does not carry gradients; use forward() (mean, std) "
+                                      "for training or call under torch.no_grad()")
         _, _, latent = hip_ops.odeconvgru_encode(self._packed(), inputs, timesteps, want_latent=True)
         return latent[:, -1], latent
