@@ -182,6 +182,24 @@ int odehip_odeconvgru_encode(const odehip_encoder* e, const float* inputs_nchw, 
                              float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* Backward of one ConvGRU step (ConvGRUCell.forward with seq_len = 1): grad_h_next -> grad_x, grad_h and the gradients of
+ * the cell's eight parameters.  Stateless: the step is recomputed from (x, h) inside the call.  input_dim and hidden_dim
+ * must be multiples of 64. */
+typedef struct odehip_convgru_cell_bwd {
+  const float* w_gates_dx;     /* odehip_pack_conv_weight(conv_gates.0.weight[:, :input], transpose_flip = 1)               */
+  const float* w_gates_dh;     /* ... conv_gates.0.weight[:, input:]                                                       */
+  const float* w_can_dx;       /* ... conv_can.0.weight[:, :input]                                                         */
+  const float* w_can_dh;       /* ... conv_can.0.weight[:, input:]                                                         */
+} odehip_convgru_cell_bwd;
+typedef struct odehip_convgru_cell_grads {
+  float *w_gates, *b_gates, *gn_gates_w, *gn_gates_b, *w_can, *b_can, *gn_can_w, *gn_can_b;
+} odehip_convgru_cell_grads;
+size_t odehip_convgru_cell_backward_workspace_bytes(const odehip_convgru_cell* c, int batch);
+int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const odehip_convgru_cell_bwd* cb, const float* x_nchw,
+                                 const float* h_nchw, const float* grad_h_next_nchw, float* grad_x_nchw, float* grad_h_nchw,
+                                 const odehip_convgru_cell_grads* grads, int batch, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
 /* ---- training path of the encoder: `loss.backward()` through ODEConvGRUCell.forward (train_test.py:204) ---------------- */
 
 typedef struct odehip_encoder_bwd {

@@ -52,6 +52,17 @@ class EncoderDesc(ctypes.Structure):
                 ("b_head1", ctypes.c_void_p)]
 
 
+class ConvGRUCellBwd(ctypes.Structure):
+    _fields_ = [("w_gates_dx", ctypes.c_void_p), ("w_gates_dh", ctypes.c_void_p), ("w_can_dx", ctypes.c_void_p),
+                ("w_can_dh", ctypes.c_void_p)]
+
+
+class ConvGRUCellGrads(ctypes.Structure):
+    _fields_ = [("w_gates", ctypes.c_void_p), ("b_gates", ctypes.c_void_p), ("gn_gates_w", ctypes.c_void_p),
+                ("gn_gates_b", ctypes.c_void_p), ("w_can", ctypes.c_void_p), ("b_can", ctypes.c_void_p),
+                ("gn_can_w", ctypes.c_void_p), ("gn_can_b", ctypes.c_void_p)]
+
+
 class EncoderBwd(ctypes.Structure):
     _fields_ = [("f_dgrad", ConvStack), ("w_gates_dx", ctypes.c_void_p), ("w_gates_dh", ctypes.c_void_p),
                 ("w_can_dx", ctypes.c_void_p), ("w_can_dh", ctypes.c_void_p), ("w_head0_t", ctypes.c_void_p),
@@ -127,6 +138,11 @@ SIGNATURES = {
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_dopri5_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_int]),
+    "odehip_convgru_cell_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvGRUCellDesc), ctypes.c_int]),
+    "odehip_convgru_cell_backward": (ctypes.c_int, [ctypes.POINTER(ConvGRUCellDesc), ctypes.POINTER(ConvGRUCellBwd),
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.POINTER(ConvGRUCellGrads), ctypes.c_int,
+                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_encoder_train_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(EncoderDesc), ctypes.c_int, ctypes.c_int]),
     "odehip_odeconvgru_encode_train": (ctypes.c_int, [ctypes.POINTER(EncoderDesc), ctypes.c_void_p,
                                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,

@@ -60,6 +60,31 @@ class _Dopri5Odeint(torch.autograd.Function):
         return (gz0, None, None, None) + tuple(grads)
 
 
+class _CellFn(torch.autograd.Function):
+    """One ConvGRU step under autograd (csrc/convgru_backward.hip: odehip_convgru_cell_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, h, packed, *params):
+        out = hip_ops.convgru_cell_forward(packed, x.detach(), h.detach())
+        ctx.packed = packed
+        ctx.versions = tuple(p._version for p in params)
+        ctx.params = params
+        ctx.save_for_backward(x.detach(), h.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("a ConvGRUCell parameter was modified in place between forward and backward")
+        x, h = ctx.saved_tensors
+        gx, gh, grads = hip_ops.convgru_cell_backward(ctx.packed, x, h, grad_out)
+        return (gx, gh, None) + tuple(grads)
+
+
+def cell_with_grad(packed, x, h):
+    return _CellFn.apply(x, h, packed, *packed._params())
+
+
 class _EncodeFn(torch.autograd.Function):
     """ODEConvGRUCell.forward under autograd: csrc/convgru_backward.hip keeps the per-frame conv outputs and sweeps back."""
 

@@ -577,3 +577,116 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
+
+// ---- one ConvGRU step: backward of ConvGRUCell.forward(input_tensor, h_cur, seq_len = 1)   (modules/ConvGRUCell.py:55-86) ----
+// Stateless: the step is recomputed from (x, h) inside the call (two convs), then reversed.
+extern "C" size_t odehip_convgru_cell_backward_workspace_bytes(const odehip_convgru_cell* c, int batch) {
+  if (!c || batch <= 0) return 0;
+  const size_t hs = al256((size_t)batch * c->hidden * kPix * 4), xs = al256((size_t)batch * c->input * kPix * 4);
+  return 3 * xs + 14 * hs + al256((size_t)4 * batch * 3 * c->hidden * 4) + al256(sizeof(WgradPair)) +
+         al256((size_t)batch * 4 * (64 * 64 * 10 + 64) * 4);
+}
+
+extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const odehip_convgru_cell_bwd* cb, const float* x_nchw,
+                                            const float* h_nchw, const float* grad_h_next_nchw, float* grad_x_nchw,
+                                            float* grad_h_nchw, const odehip_convgru_cell_grads* gr, int batch, void* workspace,
+                                            size_t workspace_bytes, void* stream_) {
+  int rc = check_cell_desc(c);
+  if (rc != ODEHIP_OK) return rc;
+  ODEHIP_REQUIRE(cb && x_nchw && h_nchw && grad_h_next_nchw && grad_x_nchw && grad_h_nchw && gr && workspace && batch > 0,
+                 "convgru_cell_backward: bad argument");
+  ODEHIP_REQUIRE(cb->w_gates_dx && cb->w_gates_dh && cb->w_can_dx && cb->w_can_dh, "convgru_cell_backward: null transposed weight");
+  ODEHIP_REQUIRE(c->input % 64 == 0 && c->hidden % 64 == 0, "convgru_cell_backward: input_dim and hidden_dim must be multiples of 64");
+  ODEHIP_REQUIRE(workspace_bytes >= odehip_convgru_cell_backward_workspace_bytes(c, batch), "convgru_cell_backward: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int H = c->hidden, I = c->input, ks = c->ks, HG = H / 32;
+  char* base = (char*)workspace;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { float* p = (float*)(base + off); off += al256(bytes); return p; };
+  const size_t hs = (size_t)batch * H * kPix * 4, xs = (size_t)batch * I * kPix * 4;
+  float* x = take(xs);
+  float* gx_c = take(xs);
+  float* gx_out = take(xs);
+  float* h = take(hs);
+  float* gates = take(2 * hs);
+  float* z = take(hs);
+  float* rh = take(hs);
+  float* cand = take(hs);
+  float* hn = take(hs);
+  float* ghn = take(hs);
+  float* g_cand = take(hs);
+  float* g_gates = take(2 * hs);
+  float* gz_pre = take(hs);
+  float* gh_ode = take(hs);
+  float* g_rh = take(hs);
+  float* gh = take(hs);
+  float* pg = take((size_t)4 * batch * 3 * H * 4);  // [dgamma_g | dbeta_g] (2H each) then [dgamma_c | dbeta_c] (H each), per sample
+  WgradPair* table = (WgradPair*)take(sizeof(WgradPair));
+  float* slabs = take((size_t)batch * 4 * (64 * 64 * 10 + 64) * 4);
+  float* pgg = pg;
+  float* pgc = pg + (size_t)2 * batch * 2 * H;
+
+  if ((rc = odehip_nchw_to_q4(x_nchw, x, batch, I, stream)) != ODEHIP_OK) return rc;
+  if ((rc = odehip_nchw_to_q4(h_nchw, h, batch, H, stream)) != ODEHIP_OK) return rc;
+  if ((rc = odehip_nchw_to_q4(grad_h_next_nchw, ghn, batch, H, stream)) != ODEHIP_OK) return rc;
+  if ((rc = cell_step_q4(c, x, h, hn, nullptr, 0, batch, gates, z, rh, cand, stream)) != ODEHIP_OK) return rc;
+
+  auto conv_bwd = [&](const float* src, int cin, int cout, const float* wt, const BwdArgs* bw, float* dst) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src1 = src;
+    a.q1 = a.qin = cin / 4;
+    a.qout = cout / 4;
+    a.w_packed = wt;
+    a.batch = batch;
+    a.combine = bw ? 3 : 0;
+    if (bw) a.bwd = *bw;
+    a.dst = dst;
+    return launch_conv(a, ks, stream);
+  };
+  hipLaunchKernelGGL(gn_update_bwd_kernel, dim3(HG, batch), dim3(256), 0, stream, cand, c->gn_can_w, c->gn_can_b, ghn, z, h, g_cand,
+                     gz_pre, gh_ode, pgc, pgc + (size_t)batch * H, HG);
+  if ((rc = conv_bwd(g_cand, H, I, cb->w_can_dx, nullptr, gx_c)) != ODEHIP_OK) return rc;
+  if ((rc = conv_bwd(g_cand, H, H, cb->w_can_dh, nullptr, g_rh)) != ODEHIP_OK) return rc;
+  hipLaunchKernelGGL(gn_gates_bwd_kernel, dim3(2 * HG, batch), dim3(256), 0, stream, gates, c->gn_gates_w, c->gn_gates_b, gz_pre, g_rh, h,
+                     gh_ode, g_gates, pgg, pgg + (size_t)batch * 2 * H, HG);
+  BwdArgs w;
+  memset(&w, 0, sizeof(w));
+  w.n_targets = 1;
+  w.tgt[0].out = gx_out;  // gradient of x = can-conv part + gates-conv part
+  w.tgt[0].srcA = gx_c;
+  w.tgt[0].a_c = 1.0f;
+  w.tgt[0].g_c = 1.0f;
+  if ((rc = conv_bwd(g_gates, 2 * H, I, cb->w_gates_dx, &w, nullptr)) != ODEHIP_OK) return rc;
+  w.tgt[0].out = gh;
+  w.tgt[0].srcA = gh_ode;
+  if ((rc = conv_bwd(g_gates, 2 * H, H, cb->w_gates_dh, &w, nullptr)) != ODEHIP_OK) return rc;
+  if ((rc = odehip_q4_to_nchw(gx_out, grad_x_nchw, batch, I, stream)) != ODEHIP_OK) return rc;
+  if ((rc = odehip_q4_to_nchw(gh, grad_h_nchw, batch, H, stream)) != ODEHIP_OK) return rc;
+
+  WgradPair pr;
+  memset(&pr, 0, sizeof(pr));
+  pr.scale = 1.0f;
+  struct Job { const float* g; int g_ch; const float* a2; float* dw; float* db; } jobs[2] = {{g_gates, 2 * H, h, gr->w_gates, gr->b_gates},
+                                                                                          {g_cand, H, rh, gr->w_can, gr->b_can}};
+  for (int j = 0; j < 2; ++j)
+    for (int half = 0; half < 2; ++half) {
+      pr.g = jobs[j].g;
+      pr.a = half == 0 ? x : jobs[j].a2;
+      if ((rc = upload_bytes(table, &pr, sizeof(pr), stream)) != ODEHIP_OK) return rc;
+      const int a_ch = half == 0 ? I : H;
+      for (int co0 = 0; co0 < jobs[j].g_ch; co0 += 64)
+        for (int ci0 = 0; ci0 < a_ch; ci0 += 64) {
+          rc = launch_wgrad_tile(table, 1, batch, 4, slabs, jobs[j].dw, jobs[j].db, ks, I + H, co0, half * I + ci0, jobs[j].g_ch / 4,
+                                 co0 / 4, a_ch / 4, ci0 / 4, half == 0 && ci0 == 0, stream);
+          if (rc != ODEHIP_OK) return rc;
+        }
+    }
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, stream, pgg, batch, 2 * H, gr->gn_gates_w);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, stream, pgg + (size_t)batch * 2 * H, batch, 2 * H,
+                     gr->gn_gates_b);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, pgc, batch, H, gr->gn_can_w);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, pgc + (size_t)batch * H, batch, H, gr->gn_can_b);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}

@@ -402,6 +402,34 @@ def convgru_cell_forward(packed_cell, x, h):
     return out
 
 
+def convgru_cell_backward(packed_cell, x, h, grad_h_next):
+    """Backward of one ConvGRU step: (grad_x, grad_h, [gradients of packed_cell._params()])."""
+    for t_, n_ in ((x, "input_tensor"), (h, "h_cur"), (grad_h_next, "grad_h_next")):
+        require_device_tensor(t_, n_)
+    d = packed_cell.refresh()
+    cached = getattr(packed_cell, "_bwd", None)
+    if cached is None or cached[0] is not packed_cell._stamp:
+        cell, i = packed_cell.cell, d.input
+        wg, wc = cell.conv_gates[0].weight.detach(), cell.conv_can[0].weight.detach()
+        keep = [pack_conv_weight(wg[:, :i], True), pack_conv_weight(wg[:, i:], True), pack_conv_weight(wc[:, :i], True),
+                pack_conv_weight(wc[:, i:], True)]
+        bw = _lib.ConvGRUCellBwd(*[k.data_ptr() for k in keep])
+        cached = packed_cell._bwd = (packed_cell._stamp, bw, keep)
+    bw = cached[1]
+    x, h, grad_h_next = x.contiguous(), h.contiguous(), grad_h_next.contiguous()
+    b = x.shape[0]
+    params = packed_cell._params()
+    grads = [torch.empty_like(p) for p in params]
+    g = _lib.ConvGRUCellGrads(*[t_.data_ptr() for t_ in grads])
+    gx, gh = torch.empty_like(x), torch.empty_like(h)
+    lib = _lib.load()
+    nbytes = lib.odehip_convgru_cell_backward_workspace_bytes(ctypes.byref(d), b)
+    ws = workspace(("cgru_bwd", b, d.input, d.hidden), nbytes, x.device)
+    _lib.check(lib.odehip_convgru_cell_backward(ctypes.byref(d), ctypes.byref(bw), _ptr(x), _ptr(h), _ptr(grad_h_next), _ptr(gx),
+                                                _ptr(gh), ctypes.byref(g), b, _ptr(ws), ws.numel(), _stream()))
+    return gx, gh, grads
+
+
 class PackedEncoder:
     """Everything `ODEConvGRUCell.forward` needs on the device: encoder dynamics, cell, 1x1 head."""
 

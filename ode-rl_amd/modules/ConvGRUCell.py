@@ -45,6 +45,10 @@ class ConvGRUCell(nn.Module):
                 x = torch.zeros(h_cur.size(0), self.input_channels, self.height, self.width, device=dev)
             else:
                 x = input_tensor[index, ...]
-            h_cur = hip_ops.convgru_cell_forward(self._packed(), x, h_cur)
+            if torch.is_grad_enabled() and (x.requires_grad or h_cur.requires_grad or any(p.requires_grad for p in self.parameters())):
+                from ..autograd import cell_with_grad
+                h_cur = cell_with_grad(self._packed(), x, h_cur)
+            else:
+                h_cur = hip_ops.convgru_cell_forward(self._packed(), x, h_cur)
             outs.append(h_cur)
         return torch.stack(outs, dim=dim), h_cur
