@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--method", default="rk4")
     p.add_argument("--train", action="store_true", help="time forward + backward (gradients w.r.t. z0 and all weights)")
     p.add_argument("--adjoint", action="store_true", help="--train through odeint_adjoint (dopri5: seminorm) instead of backward through the solver")
+    p.add_argument("--global-step-control", action="store_true",
+                   help="dopri5 on N > 1 ranks: one error norm over the global batch (an all-reduce per attempted step)")
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,6 +134,10 @@ def main():
     t_cpu = torch.arange(T, 2 * T, dtype=torch.float64) / (2 * T)
     t = t_cpu.to(dev)
 
+    if dist is not None and a.method == "dopri5" and a.global_step_control:
+        from ode_rl_amd.dist import enable_global_step_control
+        enable_global_step_control(dev)
+
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
@@ -207,7 +213,8 @@ def main():
                                                                 else f"fixed-step {a.method} (3/8 rule)") + ", f = 5x conv3x3(64->64)+ReLU, "
                                    + (("forward + adjoint backward" + (" (seminorm)" if a.method == "dopri5" else "") if a.adjoint else
                                        "forward + backward (discretise-then-optimise)") if a.train else "forward only (BASELINE configs[1])"),
-                       "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}",
+                       "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}" + (", exact-global dopri5 step control" if (a.method == "dopri5" and a.global_step_control and world > 1)
+                                                                     else (", per-shard dopri5 step control" if (a.method == "dopri5" and world > 1) else "")),
                        "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None,
                        "n_accept": int(ode_rl_amd.last_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>", "achieved": achieved,

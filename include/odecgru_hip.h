@@ -232,6 +232,16 @@ int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const odehip_enco
 
 /* ---- odeint, adaptive dopri5 (torchdiffeq Dopri5Solver; the reference's default method, configs.yaml:79) ------ */
 
+/* Exact-global step control when the batch is sharded over ranks: torchdiffeq's error norm is one RMS
+ * over the WHOLE batch.  With a callback installed, odehip_odeint_dopri5 hands every sum of squares (n <= 4 floats in
+ * `scratch_dev`, device memory the caller owns) to `cb`, which must enqueue an in-place SUM all-reduce of scratch_dev[0..n)
+ * over the ranks on `stream` (RCCL) and return 0; element counts are multiplied by world_size.  All ranks then take the same
+ * accept/reject decisions as one device holding the whole batch (up to summation order).  One collective per attempted step
+ * (plus two for the initial step): latency-bound, and the host no longer runs one attempt ahead.  cb = NULL restores
+ * per-shard control. */
+typedef int (*odehip_allreduce_fn)(float* scratch_dev, int n, void* stream, void* user);
+int odehip_set_norm_allreduce(odehip_allreduce_fn cb, void* user, int world_size, float* scratch_dev);
+
 size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times);
 
 /* Same tensors as odehip_odeint_fixed.  rtol/atol as passed by DiffEqSolver (modules/DiffEqSolver.py:13: 1e-4, 1e-5).

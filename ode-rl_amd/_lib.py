@@ -77,6 +77,9 @@ class EncoderGrads(ctypes.Structure):
                 ("b_head0", ctypes.c_void_p), ("w_head1", ctypes.c_void_p), ("b_head1", ctypes.c_void_p)]
 
 
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+
+
 class OdeHipError(RuntimeError):
     pass
 
@@ -88,6 +91,7 @@ SIGNATURES = {
     "odehip_last_error": (ctypes.c_char_p, []),
     "odehip_version": (ctypes.c_int, []),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
+    "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),
     "odehip_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "odehip_pack_conv_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,

@@ -315,6 +315,28 @@ __global__ void init_state_kernel(DopriState* st, float rtol, float atol, int n_
 
 static Mailbox* g_mailbox = nullptr;
 
+// exact-global step control under batch sharding: every sum of squares is summed over the ranks before it is used
+static odehip_allreduce_fn g_reduce_cb = nullptr;
+static void* g_reduce_user = nullptr;
+static int g_reduce_world = 1;
+static float* g_reduce_buf = nullptr;
+
+// out[j] = fixed-order sum of partial array j (one workgroup)
+struct SumSet {
+  const float* p[4];
+  int n[4];
+  int count;
+};
+__global__ __launch_bounds__(256) void sum_partials_kernel(SumSet ss, float* __restrict__ out, const int* skip) {
+  __shared__ float sh[256];
+  if (skip && *skip) return;
+  for (int j = 0; j < ss.count; ++j) {
+    const float s = block_sum(ss.p[j], ss.n[j], sh);
+    if (threadIdx.x == 0) out[j] = s;
+    __syncthreads();
+  }
+}
+
 static double now_s() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -331,6 +353,22 @@ int max_hidden(const odehip_convstack* f);
 using namespace odehip;
 
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int odehip_set_norm_allreduce(odehip_allreduce_fn cb, void* user, int world_size, float* scratch_dev) {
+  if (!cb) {
+    g_reduce_cb = nullptr;
+    g_reduce_user = nullptr;
+    g_reduce_world = 1;
+    g_reduce_buf = nullptr;
+    return ODEHIP_OK;
+  }
+  ODEHIP_REQUIRE(world_size >= 1 && scratch_dev, "set_norm_allreduce: world_size must be >= 1 and scratch_dev non-null");
+  g_reduce_cb = cb;
+  g_reduce_user = user;
+  g_reduce_world = world_size;
+  g_reduce_buf = scratch_dev;
+  return ODEHIP_OK;
+}
 
 // Workspace: [state | t_out[T] | partials x3 | ping | pong | xs | y | y1 | k1..k7]
 extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times) {
@@ -387,8 +425,24 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   for (int i = 0; i < 7; ++i) k[i] = (float*)take(st_b);
   const int* skip = &state->done;
 
-  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, state, rtol, atol, n_times, n_conv_partials,
-                     (long long)st_f, max_steps);
+  // exact-global mode: the kernels below read ONE already all-reduced scalar instead of the local partial arrays
+  const bool global_norm = g_reduce_cb != nullptr;
+  auto reduce_sums = [&](int count, const float* const* arrays, const int* lens, const int* skip_flag) -> int {
+    SumSet ss;
+    memset(&ss, 0, sizeof(ss));
+    ss.count = count;
+    for (int j = 0; j < count; ++j) {
+      ss.p[j] = arrays[j];
+      ss.n[j] = lens[j];
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, ss, g_reduce_buf, skip_flag);
+    ODEHIP_CHECK_HIP(hipGetLastError());
+    const int rcb = g_reduce_cb(g_reduce_buf, count, stream_, g_reduce_user);
+    ODEHIP_REQUIRE(rcb == 0, "odeint_dopri5: the all-reduce callback failed (%d)", rcb);
+    return ODEHIP_OK;
+  };
+  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, state, rtol, atol, n_times,
+                     global_norm ? 1 : n_conv_partials, (long long)st_f * (global_norm ? g_reduce_world : 1), max_steps);
   for (int o = 0; o < n_times; o += 32) {
     DoublePack p;
     const int m = n_times - o < 32 ? n_times - o : 32;
@@ -423,7 +477,14 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   } else {
     hipLaunchKernelGGL(scaled_sumsq_kernel, dim3(red_grid), dim3(256), 0, stream, y, (const float*)nullptr, y, atol, rtol, n4, part0);
     hipLaunchKernelGGL(scaled_sumsq_kernel, dim3(red_grid), dim3(256), 0, stream, k[0], (const float*)nullptr, y, atol, rtol, n4, part1);
-    hipLaunchKernelGGL(init1_kernel, dim3(1), dim3(256), 0, stream, state, part0, part1, red_grid);
+    if (global_norm) {
+      const float* arr[2] = {part0, part1};
+      const int lens[2] = {red_grid, red_grid};
+      if ((rc = reduce_sums(2, arr, lens, nullptr)) != ODEHIP_OK) return rc;
+      hipLaunchKernelGGL(init1_kernel, dim3(1), dim3(256), 0, stream, state, g_reduce_buf, g_reduce_buf + 1, 1);
+    } else {
+      hipLaunchKernelGGL(init1_kernel, dim3(1), dim3(256), 0, stream, state, part0, part1, red_grid);
+    }
     lc.c[0] = 1.0f;
     lc.h_ptr = &state->h0;
     hipLaunchKernelGGL(lincomb_kernel, dim3(1024), dim3(256), 0, stream, lc, n4);
@@ -431,7 +492,14 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
     rc = enqueue_f(f, xs, batch, ping, pong, &c, nullptr, nullptr, stream);
     if (rc != ODEHIP_OK) return rc;
     hipLaunchKernelGGL(scaled_sumsq_kernel, dim3(red_grid), dim3(256), 0, stream, k[1], k[0], y, atol, rtol, n4, part2);
-    hipLaunchKernelGGL(init2_kernel, dim3(1), dim3(256), 0, stream, state, part2, red_grid, t_dev);
+    if (global_norm) {
+      const float* arr[1] = {part2};
+      const int lens[1] = {red_grid};
+      if ((rc = reduce_sums(1, arr, lens, nullptr)) != ODEHIP_OK) return rc;
+      hipLaunchKernelGGL(init2_kernel, dim3(1), dim3(256), 0, stream, state, g_reduce_buf, 1, t_dev);
+    } else {
+      hipLaunchKernelGGL(init2_kernel, dim3(1), dim3(256), 0, stream, state, part2, red_grid, t_dev);
+    }
   }
   lc.c[0] = (float)kBeta[0][0];
   lc.h_ptr = &state->h;
@@ -451,7 +519,9 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   fa.state_floats = (long long)st_f;
 
   // ---- attempted steps; the host runs at most RUN_AHEAD attempts ahead of the device
-  const int RUN_AHEAD = 1;  // one attempt queued behind the running one keeps the GPU busy (enqueue ~0.1 ms < attempt ~0.4 ms)
+  // one attempt queued behind the running one keeps the GPU busy (enqueue ~0.1 ms < attempt ~0.4 ms).  Exact-global mode
+  // enqueues a collective per attempt, so every rank must enqueue the same number of attempts: no run-ahead there.
+  const int RUN_AHEAD = global_norm ? 0 : 1;
   const double t_start = now_s();
   int enq = 0;
   for (;;) {
@@ -476,7 +546,12 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
       rc = enqueue_f(f, s < 7 ? xs : y1, batch, ping, pong, &c, nullptr, skip, stream);
       if (rc != ODEHIP_OK) return rc;
     }
-    hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, part0, t_dev, g_mailbox);
+    if (global_norm) {
+      const float* arr[1] = {part0};
+      const int lens[1] = {n_conv_partials};
+      if ((rc = reduce_sums(1, arr, lens, nullptr)) != ODEHIP_OK) return rc;
+    }
+    hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, global_norm ? g_reduce_buf : part0, t_dev, g_mailbox);
     hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, stream, fa, n4, (float)kCMid[0], (float)kCMid[2],
                        (float)kCMid[3], (float)kCMid[4], (float)kCMid[5], (float)kCMid[6]);
     ODEHIP_CHECK_HIP(hipGetLastError());

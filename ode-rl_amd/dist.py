@@ -78,3 +78,39 @@ def gather_batch(x_local, group=None):
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad, group=group)
     return torch.cat([o[:int(s)] for o, s in zip(outs, sizes)], 0)
+
+
+_global_ctl = None   # (callback object, scratch tensor, group): kept alive while installed
+
+
+def enable_global_step_control(device, group=None):
+    """dopri5 under batch sharding with torchdiffeq's semantics: ONE error norm over the whole (global) batch.
+
+    Installs an all-reduce hook in the HIP library (include/odecgru_hip.h: odehip_set_norm_allreduce): every sum of squares
+    the step controller uses is summed over the ranks of `group` first (a 4..8-byte RCCL all-reduce per attempted step), so
+    all ranks take the accept/reject decisions a single device holding the full batch would take.  Every rank must call
+    odeint the same number of times with the same t.  Without it each rank adapts on its own shard (agrees to O(rtol))."""
+    global _global_ctl
+    import ctypes
+    from . import _lib
+    scratch = torch.zeros(8, dtype=torch.float32, device=device)
+    world = dist.get_world_size(group)
+
+    def _cb(ptr, n, stream, user):
+        try:
+            dist.all_reduce(scratch[:n], op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception:   # must not propagate through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = _lib.ALLREDUCE_FN(_cb)
+    _lib.check(_lib.load().odehip_set_norm_allreduce(ctypes.cast(cb, ctypes.c_void_p), None, world, scratch.data_ptr()))
+    _global_ctl = (cb, scratch, group)
+
+
+def disable_global_step_control():
+    global _global_ctl
+    from . import _lib
+    _lib.check(_lib.load().odehip_set_norm_allreduce(None, None, 1, None))
+    _global_ctl = None
