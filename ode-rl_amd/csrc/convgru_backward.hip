@@ -221,14 +221,20 @@ __global__ __launch_bounds__(256) void merge_mean_std_grad_kernel(const float* _
   *(f32x4*)(dst + (size_t)idx * 4) = v;
 }
 
-// out[c] = sum_k part[k][c] in a fixed order
+// out[c] = sum_k part[k][c] in a fixed order: one workgroup per column, strided partial sums + a fixed LDS tree
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int n_rows, int n_cols,
                                                           float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= n_cols) return;
+  __shared__ float sh[256];
+  const int c = blockIdx.x;
   float s = 0.0f;
-  for (int k = 0; k < n_rows; ++k) s += part[(size_t)k * n_cols + c];
-  out[c] = s;
+  for (int k = threadIdx.x; k < n_rows; k += 256) s += part[(size_t)k * n_cols + c];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = sh[0];
 }
 
 struct U32Pack {
@@ -570,10 +576,10 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
       }
   }
   // GroupNorm affine parameters
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, pgg, T * batch, 2 * C, gr->gn_gates_w);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, pgg + pgg_half, T * batch, 2 * C, gr->gn_gates_b);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pgc, T * batch, C, gr->gn_can_w);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, pgc + pgc_half, T * batch, C, gr->gn_can_b);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(2 * C), dim3(256), 0, stream, pgg, T * batch, 2 * C, gr->gn_gates_w);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(2 * C), dim3(256), 0, stream, pgg + pgg_half, T * batch, 2 * C, gr->gn_gates_b);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(C), dim3(256), 0, stream, pgc, T * batch, C, gr->gn_can_w);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(C), dim3(256), 0, stream, pgc + pgc_half, T * batch, C, gr->gn_can_b);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
@@ -682,11 +688,11 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
           if (rc != ODEHIP_OK) return rc;
         }
     }
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, stream, pgg, batch, 2 * H, gr->gn_gates_w);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, stream, pgg + (size_t)batch * 2 * H, batch, 2 * H,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(2 * H), dim3(256), 0, stream, pgg, batch, 2 * H, gr->gn_gates_w);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(2 * H), dim3(256), 0, stream, pgg + (size_t)batch * 2 * H, batch, 2 * H,
                      gr->gn_gates_b);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, pgc, batch, H, gr->gn_can_w);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, pgc + (size_t)batch * H, batch, H, gr->gn_can_b);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(H), dim3(256), 0, stream, pgc, batch, H, gr->gn_can_w);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(H), dim3(256), 0, stream, pgc + (size_t)batch * H, batch, H, gr->gn_can_b);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

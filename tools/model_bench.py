@@ -1,0 +1,77 @@
+"""Context numbers: end-to-end ODEConvGRU forward and training step on one GPU, with the time of each
+part (conv encoder / ODEConvGRUCell / DiffEqSolver / conv decoder).  Synthetic Moving-MNIST-shaped frames.
+  python tools/model_bench.py [--batch 64] [--frames 10] [--method rk4] [--steps 10]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--batch", type=int, default=64)
+    p.add_argument("--frames", type=int, default=10)
+    p.add_argument("--method", default="rk4")
+    p.add_argument("--steps", type=int, default=10)
+    a = p.parse_args()
+    from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    opt = argparse.Namespace(resolution=64, n_downs=2, conv_encoder_out_ch=64, in_channels=1, n_ode_layers=3,
+                             neural_ode_n_units=64, neural_ode_decoder_out_ch=64, decode_diff_method=a.method, mem=False,
+                             z_sample=False)
+    m = ODEConvGRU(opt, torch.device("cpu")).to(dev)
+    T = a.frames
+    frames = torch.rand(a.batch, T, 1, 64, 64, device=dev)
+    truth = torch.rand(a.batch, T, 1, 64, 64, device=dev)
+    ts = torch.arange(2 * T, dtype=torch.float64, device=dev) / (2 * T)
+    bd = {"observed_tp": ts[:T], "tp_to_predict": ts[T:]}
+    optim = torch.optim.Adam(m.parameters(), lr=1e-4)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def fwd():
+        with torch.no_grad():
+            return m(frames, bd)
+
+    def train():
+        optim.zero_grad(set_to_none=False)
+        loss = m.get_loss(m(frames, bd), truth)
+        loss.backward()
+        optim.step()
+
+    res = {"batch": a.batch, "frames_in": T, "frames_out": T, "method": a.method}
+    res["forward_ms"] = timed(fwd, a.steps)
+    res["train_step_ms"] = timed(train, a.steps)
+    # parts of the forward
+    with torch.no_grad():
+        b, t, c, h, w = frames.shape
+        x = frames.view(b * t, c, h, w)
+        res["conv_encoder_ms"] = timed(lambda: m.conv_encoder(x), a.steps)
+        enc = m.conv_encoder(x)
+        enc = enc.view(b, t, *enc.shape[1:]).permute(1, 0, 2, 3, 4).contiguous()
+        res["odeconvgru_cell_ms"] = timed(lambda: m.ode_convgru_cell(enc, bd["observed_tp"]), a.steps)
+        z0, _ = m.ode_convgru_cell(enc, bd["observed_tp"])
+        res["diffeq_solver_ms"] = timed(lambda: m.diffeq_solver(z0, bd["tp_to_predict"]), a.steps)
+        sol = m.diffeq_solver(z0, bd["tp_to_predict"])
+        s2 = sol.view(-1, *sol.shape[2:])
+        res["conv_decoder_ms"] = timed(lambda: torch.sigmoid(m.conv_decoder(s2)), a.steps)
+    res["pred_frames_per_s_forward"] = a.batch * T / (res["forward_ms"] * 1e-3)
+    res["pred_frames_per_s_train"] = a.batch * T / (res["train_step_ms"] * 1e-3)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
