@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); the bf16 conv is NOT bound by it (launch boundary, staging, epilogue)
 
 
 def profiled_traffic():
@@ -48,6 +49,8 @@ def parse():
     p.add_argument("--adjoint", action="store_true", help="--train through odeint_adjoint (dopri5: seminorm) instead of backward through the solver")
     p.add_argument("--global-step-control", action="store_true",
                    help="dopri5 on N > 1 ranks: one error norm over the global batch (an all-reduce per attempted step)")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                   help="compute dtype of the 3x3 convs: f32 (headline, exact) or bf16 operands + fp32 accumulate/state (configs[4])")
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,6 +120,8 @@ def main():
     torch.cuda.set_device(dev)
 
     import ode_rl_amd
+    if a.dtype == "bf16":
+        ode_rl_amd.set_compute_dtype("bf16")
     torch.manual_seed(0)
     f = ode_rl_amd.ODEFunc(n_inputs=64, n_outputs=64, n_layers=3, n_units=64, downsize=False, nonlinear="relu",
                            final_act=False)
@@ -207,7 +212,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": wall / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
                                    f"({T - 1} intervals), " + (f"adaptive dopri5 rtol {solver.odeint_rtol:g} atol {solver.odeint_atol:g}" if a.method == "dopri5"
                                                                 else f"fixed-step {a.method} (3/8 rule)") + ", f = 5x conv3x3(64->64)+ReLU, "
@@ -217,9 +222,10 @@ def main():
                                                                      else (", per-shard dopri5 step control" if (a.method == "dopri5" and world > 1) else "")),
                        "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None,
                        "n_accept": int(ode_rl_amd.last_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>", "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": profiled_traffic() if a.batch == 64 else None,
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>" if a.dtype == "f32" else "conv3x3_bf16_kernel<4>",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
+                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32") else None,
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
                          "launches_timed": launches},
         }

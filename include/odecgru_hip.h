@@ -62,6 +62,10 @@ int odehip_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int 
  * Winograd kernel.  Optional: a conv with w_wino == NULL runs the direct kernel. */
 size_t odehip_winograd_weight_floats(int cout, int cin);
 int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cout, int cin, int transpose_flip, void* stream);
+/* bf16 A-operand image of a 3x3 weight (round to nearest even): cout % 32 == 0, cin % 16 == 0, cin <= 128 is what the
+ * bf16 kernel serves; odehip_bf16_weight_bytes(cout, cin) bytes.  transpose_flip as odehip_pack_conv_weight. */
+size_t odehip_bf16_weight_bytes(int cout, int cin);
+int odehip_pack_conv_weight_bf16(const float* w_oihw, void* w_bf16, int cout, int cin, int transpose_flip, void* stream);
 
 int odehip_nchw_to_q4(const float* src_nchw, float* dst_q4, int batch, int channels, void* stream);
 int odehip_q4_to_nchw(const float* src_q4, float* dst_nchw, int batch, int channels, void* stream);
@@ -74,6 +78,7 @@ typedef struct odehip_conv_desc {
   int cin1, cin, cout, ks, batch;
   const float* w_packed;  /* from odehip_pack_conv_weight                                      */
   const float* w_wino;    /* from odehip_pack_conv_weight_winograd, or NULL (direct kernel)    */
+  const void* w_bf16;     /* from odehip_pack_conv_weight_bf16: non-NULL = bf16 operands, fp32 accumulate (3x3) */
   const float* bias;      /* cout floats or NULL                                               */
   float* dst;             /* Q4 output                                                        */
   int relu;               /* fuse ReLU into the epilogue                                      */
@@ -91,6 +96,8 @@ typedef struct odehip_convstack {
   int channels[ODEHIP_MAX_LAYERS + 1];   /* channels[i] -> channels[i+1]                            */
   const float* w_packed[ODEHIP_MAX_LAYERS];
   const float* w_wino[ODEHIP_MAX_LAYERS];  /* optional Winograd forms (3x3 layers), NULL entries run the direct kernel */
+  const void* w_bf16[ODEHIP_MAX_LAYERS];   /* optional bf16 forms: a non-NULL entry runs that layer with bf16 operands and fp32
+                                              accumulation (BASELINE.json configs[4]); state and stage combines stay fp32 */
   const float* bias[ODEHIP_MAX_LAYERS];
   int final_tanh;                        /* final_act=True appends Tanh (helpers/utils.py:179-181)  */
 } odehip_convstack;

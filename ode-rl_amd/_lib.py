@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
         ("src1", ctypes.c_void_p), ("src2", ctypes.c_void_p),
         ("cin1", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ks", ctypes.c_int),
         ("batch", ctypes.c_int),
-        ("w_packed", ctypes.c_void_p), ("w_wino", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("w_packed", ctypes.c_void_p), ("w_wino", ctypes.c_void_p), ("w_bf16", ctypes.c_void_p), ("bias", ctypes.c_void_p),
         ("dst", ctypes.c_void_p), ("relu", ctypes.c_int),
     ]
 
@@ -34,6 +34,7 @@ class ConvStack(ctypes.Structure):
         ("channels", ctypes.c_int * (MAX_LAYERS + 1)),
         ("w_packed", ctypes.c_void_p * MAX_LAYERS),
         ("w_wino", ctypes.c_void_p * MAX_LAYERS),
+        ("w_bf16", ctypes.c_void_p * MAX_LAYERS),
         ("bias", ctypes.c_void_p * MAX_LAYERS),
         ("final_tanh", ctypes.c_int),
     ]
@@ -90,6 +91,9 @@ _lib = None
 SIGNATURES = {
     "odehip_last_error": (ctypes.c_char_p, []),
     "odehip_version": (ctypes.c_int, []),
+    "odehip_bf16_weight_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "odehip_pack_conv_weight_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_void_p]),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
     "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),

@@ -7,9 +7,18 @@ import torch
 from . import hip_ops
 
 
+def _pinned(fn):
+    """backward runs with the compute dtype its forward ran with (autocast is not active on the autograd thread)."""
+    def wrapper(ctx, *grads):
+        with hip_ops.compute_mode(ctx.mode):
+            return fn(ctx, *grads)
+    return wrapper
+
+
 class _FixedGridOdeint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y0, t_host, method, stack, *params):
+        ctx.mode = hip_ops.current_compute_dtype()
         out, ws = hip_ops.odeint_fixed(stack, method, y0.detach(), t_host, save=True)
         ctx.stack, ctx.method, ctx.t_host, ctx.batch, ctx.ws = stack, method, t_host, y0.shape[0], ws
         ctx.versions = tuple(p._version for p in params)
@@ -17,6 +26,7 @@ class _FixedGridOdeint(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_pinned
     def backward(ctx, grad_out):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
@@ -33,6 +43,7 @@ class _Dopri5Odeint(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y0, t_host, cfg, stack, *params):
+        ctx.mode = hip_ops.current_compute_dtype()
         y0d = y0.detach()
         out, stats = hip_ops.odeint_dopri5(stack, y0d, t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
                                            max_steps=cfg["max_num_steps"])
@@ -49,6 +60,7 @@ class _Dopri5Odeint(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_pinned
     def backward(ctx, grad_out):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
@@ -65,6 +77,7 @@ class _CellFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, packed, *params):
+        ctx.mode = hip_ops.current_compute_dtype()
         out = hip_ops.convgru_cell_forward(packed, x.detach(), h.detach())
         ctx.packed = packed
         ctx.versions = tuple(p._version for p in params)
@@ -73,6 +86,7 @@ class _CellFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_pinned
     def backward(ctx, grad_out):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a ConvGRUCell parameter was modified in place between forward and backward")
@@ -90,6 +104,7 @@ class _EncodeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inputs, timesteps, enc, *params):
+        ctx.mode = hip_ops.current_compute_dtype()
         mean, std, saved = hip_ops.odeconvgru_encode_train(enc, inputs.detach(), timesteps)
         ctx.enc, ctx.saved = enc, saved
         ctx.versions = tuple(p._version for p in params)
@@ -97,6 +112,7 @@ class _EncodeFn(torch.autograd.Function):
         return mean, std
 
     @staticmethod
+    @_pinned
     def backward(ctx, grad_mean, grad_std):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("an encoder parameter was modified in place between forward and backward")
@@ -116,6 +132,7 @@ class _AdjointOdeint(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y0, t_host, method, stack, *params):
+        ctx.mode = hip_ops.current_compute_dtype()
         out = hip_ops.odeint_fixed(stack, method, y0.detach(), t_host)
         ctx.stack, ctx.method, ctx.t_host = stack, method, t_host
         ctx.versions = tuple(p._version for p in params)
@@ -124,6 +141,7 @@ class _AdjointOdeint(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_pinned
     def backward(ctx, grad_out):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
@@ -141,6 +159,7 @@ class _AdjointDopri5(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y0, t_host, cfg, stack, *params):
+        ctx.mode = hip_ops.current_compute_dtype()
         out, stats = hip_ops.odeint_dopri5(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"],
                                            first_step=cfg["first_step"], max_steps=cfg["max_num_steps"])
         from .odeint import last_stats
@@ -153,6 +172,7 @@ class _AdjointDopri5(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_pinned
     def backward(ctx, grad_out):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")

@@ -98,6 +98,7 @@ int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, fl
     a.qout = f->channels[l + 1] / 4;
     a.w_packed = f->w_packed[l];
     a.w_wino = f->w_wino[l];
+    a.w_bf16 = f->w_bf16[l];
     a.bias = f->bias[l];
     a.batch = batch;
     a.skip = skip;
@@ -142,6 +143,7 @@ extern "C" int odehip_conv_q4(const odehip_conv_desc* d, void* stream) {
   a.qout = d->cout / 4;
   a.w_packed = d->w_packed;
   a.w_wino = d->w_wino;
+  a.w_bf16 = d->w_bf16;
   a.bias = d->bias;
   a.dst = d->dst;
   a.batch = d->batch;

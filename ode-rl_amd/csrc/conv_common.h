@@ -127,4 +127,129 @@ __device__ __forceinline__ void finish_err(const ConvArgs& a, float esum, int wa
   }
 }
 
+// ---- shared by the 32x32-accumulator kernels (conv_q4.hip, conv_bf16.hip)
+__device__ __forceinline__ int xcd_block_id() {
+  // blocks p and p+8 share an XCD (round-robin dispatch; speed only, never correctness): give each XCD a
+  // contiguous range of logical ids so the workgroups of one sample hit the same L2.
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  return bid;
+}
+
+// 32 biases of the tile by two wave-uniform 64-B scalar loads; lane half kq picks its 16
+__device__ __forceinline__ f32x16 bias_init(const float* bias, int ct, int kq) {
+  f32x16 acc;
+  if (bias) {
+    const f32x16 lo16 = *(const f32x16*)(bias + ct * 32);
+    const f32x16 hi16 = *(const f32x16*)(bias + ct * 32 + 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c0 = (r & 3) + 8 * (r >> 2);  // 0..27, +4 for the upper lane half
+      const float lo = c0 < 16 ? lo16[c0 & 15] : hi16[c0 & 15];
+      const float hi = (c0 + 4) < 16 ? lo16[(c0 + 4) & 15] : hi16[(c0 + 4) & 15];
+      acc[r] = kq ? hi : lo;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  }
+  return acc;
+}
+
+// ---- epilogue: lane (pixel i32, half kq) holds channel quads 2g+kq of this 32-channel tile
+__device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, int b, int ct, int P, int kq, int wave) {
+  if (!a.combine) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      if (a.relu) {
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+      }
+      const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
+      *(f32x4*)(a.dst + off) = v;
+    }
+    return;
+  }
+  if (a.combine >= 2) {
+    const BwdArgs& w = a.bwd;
+    const float hb = w.h_ptr ? *w.h_ptr : 0.0f;
+    if (a.combine == 2) {
+      const float sc = w.sc_c + w.sc_h * hb;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        v *= sc;
+        if (w.mask_src) {
+          const f32x4 mk = *(const f32x4*)(w.mask_src + off);
+          v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f;
+          v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+        }
+        *(f32x4*)(a.dst + off) = v;
+      }
+      return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
+      const f32x4 gx = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      for (int t = 0; t < w.n_targets; ++t) {
+        const BwdTarget& T = w.tgt[t];
+        f32x4 o = gx * (T.g_c + T.g_h * hb);
+        if (T.srcA) o += *(const f32x4*)(T.srcA + off) * (T.a_c + T.a_h * hb);
+        if (T.srcB) o += *(const f32x4*)(T.srcB + off) * (T.b_c + T.b_h * hb);
+        *(f32x4*)(T.out + off) = o;
+      }
+    }
+    return;
+  }
+  const CombineArgs& m = a.cmb;
+  const float h = m.h_ptr ? *m.h_ptr : 1.0f;
+  float esum = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int Q = ct * 8 + 2 * g + kq;
+    const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
+    f32x4 kc = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    kc *= m.k_scale;
+    if (m.k_out) *(f32x4*)(m.k_out + off) = kc;
+    if (m.y) {
+      const f32x4 yv = *(const f32x4*)(m.y + off);
+      f32x4 sa = kc * m.c1[m.n_prev];
+      f32x4 sb = kc * m.c2[m.n_prev];
+      f32x4 se = kc * m.ce[m.n_prev];
+      for (int j = 0; j < m.n_prev; ++j) {
+        const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
+        sa += kp * m.c1[j];
+        sb += kp * m.c2[j];
+        se += kp * m.ce[j];
+      }
+      if (m.out1) *(f32x4*)(m.out1 + off) = yv + sa * h;
+      const f32x4 o2 = yv + sb * h;
+      if (m.out2) *(f32x4*)(m.out2 + off) = o2;
+      if (m.out2_nchw) {
+        float* o = m.out2_nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
+        o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+      }
+      if (m.err_partials) {
+        const f32x4 y1 = *(const f32x4*)(m.err_y1 + off);
+        const f32x4 e = se * h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float tol = m.atol + m.rtol * fmaxf(fabsf(yv[i]), fabsf(y1[i]));
+          const float r = e[i] / tol;
+          esum += r * r;
+        }
+      }
+    }
+  }
+  if (m.err_partials) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+    if ((threadIdx.x & 63) == 0) m.err_partials[(blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave] = esum;
+  }
+}
+
+
 }  // namespace odehip

@@ -491,6 +491,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
       a.qout = e->f_enc.channels[l] / 4;
       a.w_packed = eb->f_dgrad.w_packed[l];
       a.w_wino = eb->f_dgrad.w_wino[l];
+      a.w_bf16 = eb->f_dgrad.w_bf16[l];
       a.batch = batch;
       if (l > 0) {
         a.combine = 2;

@@ -309,6 +309,7 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
       a.qout = f->channels[l] / 4;
       a.w_packed = f_dgrad->w_packed[l];
       a.w_wino = f_dgrad->w_wino[l];
+      a.w_bf16 = f_dgrad->w_bf16[l];
       a.batch = batch;
       if (l > 0) {
         a.combine = 2;
@@ -474,6 +475,7 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
       a.qout = f->channels[l] / 4;
       a.w_packed = f_dgrad->w_packed[l];
       a.w_wino = f_dgrad->w_wino[l];
+      a.w_bf16 = f_dgrad->w_bf16[l];
       a.batch = batch;
       if (l > 0) {
         a.combine = 2;

@@ -79,6 +79,7 @@ struct ConvArgs {
   const float* src2;
   const float* w_packed;
   const float* w_wino;   // Winograd-transformed weights (pack_winograd) or null
+  const void* w_bf16;    // bf16 A-operand image (pack_conv_weight_bf16) or null: non-null selects bf16 compute for 3x3 layers
   const float* bias;
   float* dst;
   int q1;      // channel quads in src1
@@ -96,6 +97,7 @@ struct ConvArgs {
 
 int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
 int launch_wino(const ConvArgs& a, hipStream_t stream);
+int launch_bf16(const ConvArgs& a, hipStream_t stream);
 extern int g_debug_flags;
 extern unsigned long long* g_debug_buf;
 

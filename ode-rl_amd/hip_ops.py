@@ -5,6 +5,7 @@ current stream.  Tensors must be CUDA fp32; anything else raises (there is no CP
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -88,10 +89,71 @@ def pack_conv_weight_winograd(w, transpose_flip=False):
     return out
 
 
+# ---- compute dtype of the 3x3 conv layers: "f32" (exact fp32 MFMA, default) or "bf16" (bf16 operands, fp32 accumulation;
+# state, stage combines and conv outputs stay fp32).  bf16 is chosen by set_compute_dtype("bf16") or, as the reference's
+# users would ask for it, by running under torch.autocast(device_type="cuda", dtype=torch.bfloat16).
+_global_mode = None
+_forced = threading.local()
+
+
+def set_compute_dtype(mode):
+    """"f32", "bf16", or None (= follow torch.autocast)."""
+    global _global_mode
+    if mode not in (None, "f32", "bf16"):
+        raise ValueError('compute dtype must be "f32", "bf16" or None')
+    _global_mode = mode
+
+
+def current_compute_dtype():
+    forced = getattr(_forced, "mode", None)
+    if forced is not None:
+        return forced
+    if _global_mode is not None:
+        return _global_mode
+    try:
+        on, dt = torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda")
+    except TypeError:   # older signatures
+        on, dt = torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype()
+    return "bf16" if (on and dt == torch.bfloat16) else "f32"
+
+
+class compute_mode:
+    """Pins the compute dtype inside a backward pass to the one its forward ran with (autocast is not active on the autograd
+    engine's thread)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = getattr(_forced, "mode", None)
+        _forced.mode = self.mode
+
+    def __exit__(self, *exc):
+        _forced.mode = self.prev
+
+
+def pack_conv_weight_bf16(w, transpose_flip=False):
+    """(Cout,Cin,3,3) fp32 -> bf16 A-operand image of the bf16 MFMA kernel (round to nearest even)."""
+    require_device_tensor(w, "weight")
+    w = w.detach().contiguous()
+    co, ci, k, k2 = w.shape
+    if (k, k2) != (3, 3):
+        raise ValueError("the bf16 kernel serves 3x3 layers only")
+    if transpose_flip:
+        co, ci = ci, co
+    out = torch.empty(co * ci * 9, dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.load().odehip_pack_conv_weight_bf16(_ptr(w), _ptr(out), co, ci, int(bool(transpose_flip)), _stream()))
+    return out
+
+
+def _bf16_ok(cin, cout, ks):
+    return ks == 3 and cin % 16 == 0 and cin <= 128 and cin // 16 in (1, 2, 4, 8) and cout % 32 == 0
+
+
 USE_WINOGRAD = os.environ.get("ODEHIP_NO_WINOGRAD") is None   # 3x3 layers with cin % 16 == 0 run the Winograd kernel (2.25x fewer MFMAs, still exact-fp32 arithmetic)
 
 
-def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False, w_wino=None):
+def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False, w_wino=None, w_bf16=None):
     """One conv layer on Q4 activations (tests / building block)."""
     require_device_tensor(src1, "src1")
     b = src1.shape[0]
@@ -101,6 +163,7 @@ def conv_q4(src1, w_packed, bias, cout, ks, src2=None, relu=False, w_wino=None):
     d = _lib.ConvDesc(src1=src1.data_ptr(), src2=src2.data_ptr() if src2 is not None else None, cin1=cin1, cin=cin,
                       cout=cout, ks=ks, batch=b, w_packed=w_packed.data_ptr(),
                       w_wino=w_wino.data_ptr() if w_wino is not None else None,
+                      w_bf16=w_bf16.data_ptr() if w_bf16 is not None else None,
                       bias=bias.data_ptr() if bias is not None else None,
                       dst=dst.data_ptr(), relu=int(relu))
     _lib.check(_lib.load().odehip_conv_q4(ctypes.byref(d), _stream()))
@@ -114,18 +177,21 @@ class PackedConvStack:
     def __init__(self, convs, final_tanh=False):
         self.convs = list(convs)
         self.final_tanh = bool(final_tanh)
-        self._stamp = None
-        self._packed = None
+        self._cache = {}      # compute dtype -> dict(stamp, desc, keep, dgrad)
         self._bias = None
         self.desc = None
 
     def _current_stamp(self):
         return tuple((c.weight.data_ptr(), c.weight._version, c.bias.data_ptr(), c.bias._version) for c in self.convs)
 
-    def refresh(self):
+    def refresh(self, mode=None):
+        mode = mode or current_compute_dtype()
         stamp = self._current_stamp()
-        if stamp == self._stamp:
-            return self.desc
+        ent = self._cache.get(mode)
+        if ent is not None and ent["stamp"] == stamp:
+            self.desc = ent["desc"]
+            self._bias = ent["bias"]
+            return ent["desc"]
         convs = self.convs
         if len(convs) > _lib.MAX_LAYERS:
             raise ValueError(f"at most {_lib.MAX_LAYERS} conv layers are supported")
@@ -136,42 +202,49 @@ class PackedConvStack:
                 raise ValueError("the HIP path supports stride-1 'same' square convs with bias only "
                                  f"(got {c}); downsize=True dynamics are not supported")
             require_device_tensor(c.weight, "conv weight")
-        self._packed = [pack_conv_weight(c.weight) for c in convs]
+        packed = [pack_conv_weight(c.weight) for c in convs]
         wino_ok = USE_WINOGRAD and ks == 3
-        self._wino = [pack_conv_weight_winograd(c.weight) if wino_ok and c.in_channels % 16 == 0 else None for c in convs]
-        self._bias = [c.bias.detach().contiguous() for c in convs]
+        wino = [pack_conv_weight_winograd(c.weight) if wino_ok and c.in_channels % 16 == 0 else None for c in convs]
+        bf16 = [pack_conv_weight_bf16(c.weight) if mode == "bf16" and _bf16_ok(c.in_channels, c.out_channels, ks) else None
+                for c in convs]
+        bias = [c.bias.detach().contiguous() for c in convs]
         d = _lib.ConvStack()
         d.n_convs = len(convs)
         d.ks = ks
         d.channels[0] = convs[0].in_channels
         for i, c in enumerate(convs):
             d.channels[i + 1] = c.out_channels
-            d.w_packed[i] = self._packed[i].data_ptr()
-            d.w_wino[i] = self._wino[i].data_ptr() if self._wino[i] is not None else None
-            d.bias[i] = self._bias[i].data_ptr()
+            d.w_packed[i] = packed[i].data_ptr()
+            d.w_wino[i] = wino[i].data_ptr() if wino[i] is not None else None
+            d.w_bf16[i] = bf16[i].data_ptr() if bf16[i] is not None else None
+            d.bias[i] = bias[i].data_ptr()
         d.final_tanh = int(self.final_tanh)
-        self.desc = d
-        self._stamp = stamp
-        self._dgrad = None
+        self._cache[mode] = dict(stamp=stamp, desc=d, keep=(packed, wino, bf16), bias=bias, dgrad=None)
+        self.desc, self._bias = d, bias
         return d
 
-    def dgrad_desc(self):
+    def dgrad_desc(self, mode=None):
         """Stack of the input-gradient convs (weights packed transposed + flipped), built on first use."""
-        d0 = self.refresh()
-        if self._dgrad is None:
+        mode = mode or current_compute_dtype()
+        d0 = self.refresh(mode)
+        ent = self._cache[mode]
+        if ent["dgrad"] is None:
             packed = [pack_conv_weight(c.weight, transpose_flip=True) for c in self.convs]
             wino = [pack_conv_weight_winograd(c.weight, transpose_flip=True)
                     if USE_WINOGRAD and d0.ks == 3 and c.out_channels % 16 == 0 else None for c in self.convs]
+            bf16 = [pack_conv_weight_bf16(c.weight, transpose_flip=True)
+                    if mode == "bf16" and _bf16_ok(c.out_channels, c.in_channels, d0.ks) else None for c in self.convs]
             d = _lib.ConvStack()
-            d.n_convs, d.ks = self.desc.n_convs, self.desc.ks
+            d.n_convs, d.ks = d0.n_convs, d0.ks
             for i in range(len(self.convs) + 1):
-                d.channels[i] = self.desc.channels[i]
+                d.channels[i] = d0.channels[i]
             for i, p in enumerate(packed):
                 d.w_packed[i] = p.data_ptr()
                 d.w_wino[i] = wino[i].data_ptr() if wino[i] is not None else None
-                d.bias[i] = self._bias[i].data_ptr()
-            self._dgrad = (d, packed, wino)
-        return self._dgrad[0]
+                d.w_bf16[i] = bf16[i].data_ptr() if bf16[i] is not None else None
+                d.bias[i] = ent["bias"][i].data_ptr()
+            ent["dgrad"] = (d, packed, wino, bf16)
+        return ent["dgrad"][0]
 
 
 def convstack_forward(stack, y, negate=False):

@@ -12,7 +12,26 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- dynamics f
-def convnet_forward(y, weights, biases, final_tanh=False):
+class _MixedConv(torch.autograd.Function):
+    """nn.Conv2d with bf16 operands and fp32 accumulation, as the HIP bf16 path computes it (BASELINE.json configs[4]):
+    forward conv(bf16(x), bf16(W)) + b in fp32; backward: input gradient from bf16(g) and bf16(W); weight/bias gradients
+    in fp32 from the unrounded x and g."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, stride=1, padding=w.shape[-1] // 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        pad = w.shape[-1] // 2
+        gx = torch.nn.grad.conv2d_input(x.shape, w.bfloat16().float(), g.bfloat16().float(), padding=pad)
+        gw = torch.nn.grad.conv2d_weight(x, w.shape, g, padding=pad)
+        return gx, gw, g.sum((0, 2, 3))
+
+
+def convnet_forward(y, weights, biases, final_tanh=False, compute_dtype="f32"):
     """`helpers/utils.py:158-183` create_convnet with nonlinear='relu':
     Conv3x3 -> [ReLU -> Conv3x3]*n_layers -> ReLU -> Conv3x3 [-> Tanh].
 
@@ -21,7 +40,10 @@ def convnet_forward(y, weights, biases, final_tanh=False):
     x = y
     n = len(weights)
     for i, (w, b) in enumerate(zip(weights, biases)):
-        x = F.conv2d(x, w, b, stride=1, padding=w.shape[-1] // 2)
+        if compute_dtype == "bf16":
+            x = _MixedConv.apply(x, w, b)
+        else:
+            x = F.conv2d(x, w, b, stride=1, padding=w.shape[-1] // 2)
         if i < n - 1:
             x = torch.relu(x)
     if final_tanh:
@@ -29,10 +51,10 @@ def convnet_forward(y, weights, biases, final_tanh=False):
     return x
 
 
-def ode_func(weights, biases, backwards=False, final_tanh=False):
+def ode_func(weights, biases, backwards=False, final_tanh=False, compute_dtype="f32"):
     """`modules/DiffEqSolver.py:57-80` ODEFunc.forward as a closure f(t, y); t is ignored."""
     def f(t, y):
-        g = convnet_forward(y, weights, biases, final_tanh)
+        g = convnet_forward(y, weights, biases, final_tanh, compute_dtype)
         return -g if backwards else g
     return f
 

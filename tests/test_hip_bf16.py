@@ -1,0 +1,113 @@
+"""bf16-compute path (BASELINE.json configs[4]: bf16 operands on the matrix cores, fp32 accumulation, fp32 solver state)
+against an emulation of exactly that arithmetic in the oracle (operands rounded to bf16, fp32 everything else):
+one conv layer rel-L2 <= 1e-5 (bf16 products are exact in fp32); a stack / trajectory <= 1e-3 and gradients <= 5e-3, because
+an activation within fp32 round-off of a bf16 rounding boundary may round the other way in two correct implementations;
+and against the exact fp32 oracle to show the size of the bf16 error itself (<= 2e-2)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    import ode_rl_amd
+    ode_rl_amd.set_compute_dtype("bf16")
+    yield
+    ode_rl_amd.set_compute_dtype(None)
+
+
+def _f(ch_in=64, units=64, seed=0):
+    import ode_rl_amd
+    torch.manual_seed(seed)
+    f = ode_rl_amd.ODEFunc(ch_in, ch_in, 3 if ch_in == 64 else 2, units, False, "relu", final_act=False)
+    return f, {k: v.detach().clone() for k, v in f.state_dict().items()}
+
+
+@pytest.mark.parametrize("ch,units,batch", [(64, 64, 3), (128, 64, 2)])
+def test_f_bf16_matches_emulation(cuda, bf16_mode, ch, units, batch):
+    from ode_rl_amd import hip_ops
+    from ode_rl_amd.odeint import conv_stack_of
+    from oracle import reference_modules as rm
+    f, sd = _f(ch, units)
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+    y = torch.randn(batch, ch, 16, 16, generator=torch.Generator().manual_seed(1)) * 0.5
+    emu = rm.convnet_forward(y, ws, bs, compute_dtype="bf16")
+    exact = rm.convnet_forward(y, ws, bs)
+    f = f.to(cuda)
+    # one layer: products of bf16 values are exact in fp32, only the summation order differs
+    c0 = f.gradient_net[0]
+    one = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(y.to(cuda)), hip_ops.pack_conv_weight(c0.weight), c0.bias.detach(),
+                                             c0.out_channels, 3, relu=True, w_bf16=hip_ops.pack_conv_weight_bf16(c0.weight)))
+    assert rel_l2(one, torch.relu(rm.convnet_forward(y, ws[:1], bs[:1], compute_dtype="bf16"))) <= 1e-5
+    # the stack: a hidden activation within fp32 round-off of a bf16 rounding boundary may round the other way in two correct
+    # implementations (a 2^-8 relative jump of that one input), so layers compound to ~1e-4
+    out = hip_ops.convstack_forward(conv_stack_of(f), y.to(cuda))
+    assert rel_l2(out, emu) <= 1e-3
+    e = rel_l2(out, exact)
+    assert 1e-4 <= e <= 2e-2, e          # really bf16 (not the fp32 kernels), and of the expected size
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_trajectory_and_gradients_bf16(cuda, bf16_mode, method):
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    f, _ = _f()
+    with torch.no_grad():   # kink-free dynamics (see test_hip_backward.py)
+        for i in (0, 2, 4, 6):
+            f.gradient_net[i].weight.mul_(0.15)
+            f.gradient_net[i].bias.copy_(torch.where(torch.arange(64) % 2 == 0, 2.5, -2.5))
+        f.gradient_net[8].weight.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+    ws = [w.requires_grad_(True) for w in ws]
+    bs = [b.requires_grad_(True) for b in bs]
+    g = torch.Generator().manual_seed(5)
+    z0 = (torch.randn(3, 64, 16, 16, generator=g) * 0.5).requires_grad_(True)
+    t = torch.tensor([0.1, 0.25, 0.3, 0.7], dtype=torch.float64)
+    gout = torch.randn(4, 3, 64, 16, 16, generator=g)
+    kw = dict(rtol=1e-3, atol=1e-4, options={"first_step": 0.05}) if method == "dopri5" else {}
+    ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs, compute_dtype="bf16"), z0, t, method=method, **kw)
+    rg = torch.autograd.grad(ref, [z0] + ws + bs, gout)
+    f = f.to(cuda)
+    zd = z0.detach().to(cuda).requires_grad_(True)
+    sol = ode_rl_amd.odeint(f, zd, t, method=method, **kw)
+    assert rel_l2(sol, ref.detach()) <= 1e-3
+    sol.backward(gout.to(cuda))
+    assert rel_l2(zd.grad, rg[0]) <= 5e-3
+    convs = [m for m in f.gradient_net if isinstance(m, torch.nn.Conv2d)]
+    for c, gw, gb in zip(convs, rg[1:6], rg[6:]):
+        assert rel_l2(c.weight.grad, gw) <= 5e-3 and rel_l2(c.bias.grad, gb) <= 5e-3
+
+
+def test_autocast_selects_bf16_and_backward_keeps_it(cuda):
+    """torch.autocast(dtype=bfloat16) is how a user of the reference asks for bf16; the backward pass, which runs outside
+    the autocast region on the autograd thread, must use the same compute dtype as its forward."""
+    import ode_rl_amd
+    f, _ = _f()
+    f = f.to(cuda)
+    z0 = torch.randn(2, 64, 16, 16, device=cuda) * 0.5
+    t = torch.tensor([0.0, 0.2, 0.5], dtype=torch.float64)
+    gout = torch.randn(3, 2, 64, 16, 16, device=cuda)
+
+    def run(ctx):
+        f.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        with ctx:
+            sol = ode_rl_amd.odeint(f, z, t, method="rk4")
+        sol.backward(gout)
+        return sol.detach(), z.grad.clone(), [p.grad.clone() for p in f.parameters()]
+    import contextlib
+    a = run(torch.autocast(device_type="cuda", dtype=torch.bfloat16))
+    ode_rl_amd.set_compute_dtype("bf16")
+    try:
+        b = run(contextlib.nullcontext())
+    finally:
+        ode_rl_amd.set_compute_dtype(None)
+    c = run(contextlib.nullcontext())
+    assert a[0].dtype == torch.float32
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+    assert not torch.equal(a[0], c[0]) and rel_l2(a[0], c[0]) <= 2e-2
