@@ -277,6 +277,14 @@ int odehip_odeint_dopri5_backward(const odehip_convstack* f, const odehip_convst
                                   const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w, float* const* grad_b,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- optimizer step of the training loop (train_test.py:24,205: optim.Adam(model.parameters(), lr)) ------------------------ */
+
+/* One launch for every parameter tensor: torch.optim.Adam arithmetic (amsgrad off; weight_decay is the L2 form), `step` counts
+ * from 1.  Host arrays of n_tensors device pointers / element counts. */
+int odehip_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     const long long* numel, int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

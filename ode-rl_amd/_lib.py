@@ -94,6 +94,10 @@ SIGNATURES = {
     "odehip_bf16_weight_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "odehip_pack_conv_weight_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_void_p]),
+    "odehip_adam_step": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
     "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),
