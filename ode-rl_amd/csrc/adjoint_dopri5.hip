@@ -28,33 +28,7 @@ namespace odehip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct WgradPair {
-  const float* g;
-  const float* a;
-  float scale;
-  float pad_[3];
-};
-int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
-                 int cin, hipStream_t stream);
-int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
-                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
-int check_stack(const odehip_convstack* f);
-int upload_floats(float* dst, const float* src, int n, hipStream_t stream);
 
-static const double aBeta[6][6] = {
-    {1.0 / 5, 0, 0, 0, 0, 0},
-    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
-    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
-    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
-    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
-    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
-};
-static const double aCSol[7] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0};
-static const double aCErr[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
-                                -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
-static const double aCMid[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
-                                -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
-                                -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
 
 // sum over elements of ((a - b) / (atol + |y|*rtol))^2, one partial per workgroup (b may be null)
 __global__ __launch_bounds__(256) void adj_sumsq_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -121,7 +95,6 @@ __global__ __launch_bounds__(256) void adj_lincomb_kernel(AdjLin a, long long n4
   }
 }
 
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct AdjLayout {
   int T, B, C, NH, max_slots, n_part;
@@ -356,7 +329,7 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
       const float h = (float)dt;
       if ((rc = upload_floats(hdev, &h, 1, stream)) != ODEHIP_OK) return rc;
       {  // stage-2 inputs from k1
-        const float c = (float)aBeta[0][0] * h;
+        const float c = (float)dp5::kBeta[0][0] * h;
         float* k0y[1] = {ky[0]};
         float* k0a[1] = {ka[0]};
         lincomb(L.xin(ws, slot, 1), y_cur, 1, k0y, &c, nullptr);
@@ -378,11 +351,11 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
         cy.k_out = ky[s - 1];
         ca.k_out = ka[s - 1];
         if (s <= 6) {
-          for (int j = 0; j < s; ++j) cy.c1[j] = ca.c1[j] = (float)aBeta[s - 1][j];
+          for (int j = 0; j < s; ++j) cy.c1[j] = ca.c1[j] = (float)dp5::kBeta[s - 1][j];
           cy.out1 = L.xin(ws, slot, s);       // Y_{s+1}  (s = 6: y1)
           ca.out1 = L.gp(ws, slot, s, NH);    // A_{s+1}  (s = 6: a1)
         } else {
-          for (int j = 0; j < 7; ++j) cy.ce[j] = ca.ce[j] = (float)aCErr[j];
+          for (int j = 0; j < 7; ++j) cy.ce[j] = ca.ce[j] = (float)dp5::kCErr[j];
           cy.err_y1 = L.xin(ws, slot, 6);
           ca.err_y1 = L.gp(ws, slot, 6, NH);
           cy.err_partials = L.part(ws, 4);
@@ -418,18 +391,11 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
       const bool final_step = t_new >= t_end;
       float w[7];
       if (!final_step) {
-        for (int s = 0; s < 7; ++s) w[s] = (float)aCSol[s] * h;
+        for (int s = 0; s < 7; ++s) w[s] = (float)dp5::kCSol[s] * h;
       } else {
         // dense output at x: a(x) - a0 = h * sum_s W_s(x) k_s  (the quartic of _interp_fit/_interp_evaluate, linear in k)
         const float x = (float)((t_end - t_cur) / (t_new - t_cur));
-        const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-        for (int s = 0; s < 7; ++s) {
-          const double d1 = s == 0 ? 1.0 : 0.0, d7 = s == 6 ? 1.0 : 0.0, b = aCSol[s], m = aCMid[s];
-          const double A4 = 2.0 * (d7 - d1) - 8.0 * b + 16.0 * m;
-          const double B3 = 5.0 * d1 - 3.0 * d7 + 14.0 * b - 32.0 * m;
-          const double C2 = d7 - 4.0 * d1 - 5.0 * b + 16.0 * m;
-          w[s] = h * (float)(x * d1 + x2 * C2 + x3 * B3 + x4 * A4);
-        }
+        for (int s = 0; s < 7; ++s) w[s] = h * (float)dp5::dense_weight(s, (double)x);
       }
       for (int s = 0; s < 7; ++s) {
         if (w[s] == 0.0f) continue;

@@ -77,8 +77,6 @@ static inline size_t state_bytes(int batch, int channels) { return (size_t)batch
 
 // Enqueue f(x) with the stage-combine fused into the last conv.  ping/pong hold hidden activations.
 // `hidden`, if given, holds n_convs-1 distinct buffers for the ReLU outputs (save_for_backward); else ping/pong.
-int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
-                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
 
 int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong, const CombineArgs* cmb,
               float* plain_dst, const int* skip, hipStream_t stream) {

@@ -23,10 +23,6 @@ namespace odehip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong, const CombineArgs* cmb,
-              float* plain_dst, const int* skip, hipStream_t stream);
-int check_stack(const odehip_convstack* f);
-int max_hidden(const odehip_convstack* f);
 
 __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 #pragma unroll
@@ -161,7 +157,6 @@ __global__ void fill64_kernel(float* dst, FloatPack64 p, int n) {
 
 using namespace odehip;
 
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 static int check_cell(const odehip_convgru_cell* c) {
   ODEHIP_REQUIRE(c, "convgru: null cell descriptor");

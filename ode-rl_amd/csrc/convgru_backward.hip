@@ -25,20 +25,6 @@ namespace odehip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct WgradPair {
-  const float* g;
-  const float* a;
-  float scale;
-  float pad_[3];
-};
-int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
-                 int cin, hipStream_t stream);
-int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
-                      int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
-                      hipStream_t stream);
-int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
-                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
-int check_stack(const odehip_convstack* f);
 
 __device__ __forceinline__ float bsum256(float v, float* sh) {
 #pragma unroll
@@ -264,7 +250,6 @@ int conv_layer_q4(const float* src1, const float* src2, int cin1, int cin, int c
 void launch_split_mean_std(const float* head_out, float* mean, float* stdv, int batch, int out_ch, hipStream_t stream);
 int check_cell_desc(const odehip_convgru_cell* c);
 
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 // Workspace of the training path; one place knows where everything lives.
 struct EncLayout {
@@ -587,11 +572,28 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
 
 // ---- one ConvGRU step: backward of ConvGRUCell.forward(input_tensor, h_cur, seq_len = 1)   (modules/ConvGRUCell.py:55-86) ----
 // Stateless: the step is recomputed from (x, h) inside the call (two convs), then reversed.
+namespace odehip {
+// Workspace of one ConvGRU-step backward; offsets are computed in ONE place for the size query and the call.
+struct CellBwdLayout {
+  size_t x, gx_c, gx_out, h, gates, z, rh, cand, hn, ghn, g_cand, g_gates, gz_pre, gh_ode, g_rh, gh, pg, table, slabs, total;
+  CellBwdLayout(const odehip_convgru_cell* c, int batch) {
+    const size_t hs = (size_t)batch * c->hidden * kPix * 4, xs = (size_t)batch * c->input * kPix * 4;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += al256(bytes); return r; };
+    x = take(xs); gx_c = take(xs); gx_out = take(xs);
+    h = take(hs); gates = take(2 * hs); z = take(hs); rh = take(hs); cand = take(hs); hn = take(hs); ghn = take(hs);
+    g_cand = take(hs); g_gates = take(2 * hs); gz_pre = take(hs); gh_ode = take(hs); g_rh = take(hs); gh = take(hs);
+    pg = take((size_t)6 * batch * c->hidden * 4);  // [dgamma_g | dbeta_g] (2H each) then [dgamma_c | dbeta_c] (H each), per sample
+    table = take(sizeof(WgradPair));
+    slabs = take((size_t)batch * 4 * (64 * 64 * 10 + 64) * 4);
+    total = o;
+  }
+};
+}  // namespace odehip
+
 extern "C" size_t odehip_convgru_cell_backward_workspace_bytes(const odehip_convgru_cell* c, int batch) {
-  if (!c || batch <= 0) return 0;
-  const size_t hs = al256((size_t)batch * c->hidden * kPix * 4), xs = al256((size_t)batch * c->input * kPix * 4);
-  return 3 * xs + 14 * hs + al256((size_t)4 * batch * 3 * c->hidden * 4) + al256(sizeof(WgradPair)) +
-         al256((size_t)batch * 4 * (64 * 64 * 10 + 64) * 4);
+  if (!c || batch <= 0 || c->hidden <= 0 || c->input <= 0) return 0;
+  return CellBwdLayout(c, batch).total;
 }
 
 extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const odehip_convgru_cell_bwd* cb, const float* x_nchw,
@@ -607,29 +609,12 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
   ODEHIP_REQUIRE(workspace_bytes >= odehip_convgru_cell_backward_workspace_bytes(c, batch), "convgru_cell_backward: workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
   const int H = c->hidden, I = c->input, ks = c->ks, HG = H / 32;
-  char* base = (char*)workspace;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { float* p = (float*)(base + off); off += al256(bytes); return p; };
-  const size_t hs = (size_t)batch * H * kPix * 4, xs = (size_t)batch * I * kPix * 4;
-  float* x = take(xs);
-  float* gx_c = take(xs);
-  float* gx_out = take(xs);
-  float* h = take(hs);
-  float* gates = take(2 * hs);
-  float* z = take(hs);
-  float* rh = take(hs);
-  float* cand = take(hs);
-  float* hn = take(hs);
-  float* ghn = take(hs);
-  float* g_cand = take(hs);
-  float* g_gates = take(2 * hs);
-  float* gz_pre = take(hs);
-  float* gh_ode = take(hs);
-  float* g_rh = take(hs);
-  float* gh = take(hs);
-  float* pg = take((size_t)4 * batch * 3 * H * 4);  // [dgamma_g | dbeta_g] (2H each) then [dgamma_c | dbeta_c] (H each), per sample
-  WgradPair* table = (WgradPair*)take(sizeof(WgradPair));
-  float* slabs = take((size_t)batch * 4 * (64 * 64 * 10 + 64) * 4);
+  const CellBwdLayout L(c, batch);
+  auto at = [&](size_t off) { return (float*)((char*)workspace + off); };
+  float *x = at(L.x), *gx_c = at(L.gx_c), *gx_out = at(L.gx_out), *h = at(L.h), *gates = at(L.gates), *z = at(L.z), *rh = at(L.rh),
+        *cand = at(L.cand), *hn = at(L.hn), *ghn = at(L.ghn), *g_cand = at(L.g_cand), *g_gates = at(L.g_gates), *gz_pre = at(L.gz_pre),
+        *gh_ode = at(L.gh_ode), *g_rh = at(L.g_rh), *gh = at(L.gh), *pg = at(L.pg), *slabs = at(L.slabs);
+  WgradPair* table = (WgradPair*)at(L.table);
   float* pgg = pg;
   float* pgc = pg + (size_t)2 * batch * 2 * H;
 

@@ -22,19 +22,6 @@ namespace odehip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Dormand-Prince-Shampine tableau (torchdiffeq/_impl/dopri5.py)
-static const double kBeta[6][6] = {
-    {1.0 / 5, 0, 0, 0, 0, 0},
-    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
-    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
-    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
-    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
-    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
-};
-static const double kCErr[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
-                                -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
-static const double kCMid[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
-                                -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
-                                -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
 
 struct DopriState {
   double t0, t1, dt;   // accepted interval [t0, t1]; size of the attempt in flight
@@ -343,16 +330,11 @@ static double now_s() {
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
-int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong, const CombineArgs* cmb,
-              float* plain_dst, const int* skip, hipStream_t stream);
-int check_stack(const odehip_convstack* f);
-int max_hidden(const odehip_convstack* f);
 
 }  // namespace odehip
 
 using namespace odehip;
 
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 extern "C" int odehip_set_norm_allreduce(odehip_allreduce_fn cb, void* user, int world_size, float* scratch_dev) {
   if (!cb) {
@@ -501,7 +483,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
       hipLaunchKernelGGL(init2_kernel, dim3(1), dim3(256), 0, stream, state, part2, red_grid, t_dev);
     }
   }
-  lc.c[0] = (float)kBeta[0][0];
+  lc.c[0] = (float)dp5::kBeta[0][0];
   lc.h_ptr = &state->h;
   hipLaunchKernelGGL(lincomb_kernel, dim3(1024), dim3(256), 0, stream, lc, n4);  // x2 of the first attempt
   ODEHIP_CHECK_HIP(hipGetLastError());
@@ -534,10 +516,10 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
       for (int j = 0; j < s - 1; ++j) c.k_prev[j] = k[j];
       c.k_out = k[s - 1];
       if (s <= 6) {
-        for (int j = 0; j < s; ++j) c.c1[j] = (float)kBeta[s - 1][j];
+        for (int j = 0; j < s; ++j) c.c1[j] = (float)dp5::kBeta[s - 1][j];
         c.out1 = s < 6 ? xs : y1;  // x7 = y1 (c_sol equals the last beta row)
       } else {
-        for (int j = 0; j < 7; ++j) c.ce[j] = (float)kCErr[j];
+        for (int j = 0; j < 7; ++j) c.ce[j] = (float)dp5::kCErr[j];
         c.err_y1 = y1;
         c.err_partials = part0;
         c.rtol = rtol;
@@ -552,8 +534,8 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
       if ((rc = reduce_sums(1, arr, lens, nullptr)) != ODEHIP_OK) return rc;
     }
     hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, global_norm ? g_reduce_buf : part0, t_dev, g_mailbox);
-    hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, stream, fa, n4, (float)kCMid[0], (float)kCMid[2],
-                       (float)kCMid[3], (float)kCMid[4], (float)kCMid[5], (float)kCMid[6]);
+    hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, stream, fa, n4, (float)dp5::kCMid[0], (float)dp5::kCMid[2],
+                       (float)dp5::kCMid[3], (float)dp5::kCMid[4], (float)dp5::kCMid[5], (float)dp5::kCMid[6]);
     ODEHIP_CHECK_HIP(hipGetLastError());
     ++enq;
     // bound the run-ahead; leave as soon as the controller reports done

@@ -25,31 +25,7 @@ namespace odehip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct WgradPair {
-  const float* g;
-  const float* a;
-  float scale;
-  float pad_[3];
-};
-int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
-                 int cin, hipStream_t stream);
-int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
-                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
-int check_stack(const odehip_convstack* f);
-int upload_floats(float* dst, const float* src, int n, hipStream_t stream);
 
-static const double bBeta[6][6] = {
-    {1.0 / 5, 0, 0, 0, 0, 0},
-    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
-    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
-    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
-    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
-    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
-};
-static const double bCSol[7] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0};
-static const double bCMid[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
-                                -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
-                                -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
 
 // out = (accumulate ? out : 0) + sum_j c[j] * src[j]
 struct MultiAxpy {
@@ -67,7 +43,6 @@ __global__ __launch_bounds__(256) void multi_axpy_kernel(MultiAxpy a, long long 
   }
 }
 
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct BwdLayout {
   int T, B, C, NH, N;
@@ -225,7 +200,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
       memset(&a, 0, sizeof(a));
       a.n = 2;
       a.src[0] = y0; a.c[0] = 1.0f;
-      a.src[1] = k[0]; a.c[1] = (float)bBeta[0][0] * (float)accepted_host[2 * n + 1];
+      a.src[1] = k[0]; a.c[1] = (float)dp5::kBeta[0][0] * (float)accepted_host[2 * n + 1];
       a.out = L.xin(ws, n, 1);
       hipLaunchKernelGGL(multi_axpy_kernel, dim3(1024), dim3(256), 0, stream, a, n4);
     }
@@ -238,7 +213,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
       for (int j = 0; j < s - 1; ++j) c.k_prev[j] = k[j];
       c.k_out = k[s - 1];
       if (s <= 6) {
-        for (int j = 0; j < s; ++j) c.c1[j] = (float)bBeta[s - 1][j];
+        for (int j = 0; j < s; ++j) c.c1[j] = (float)dp5::kBeta[s - 1][j];
         c.out1 = L.xin(ws, n, s);  // Y_{s+1}; s = 6: y1
       }
       if ((rc = run_f(n, s - 1, L.xin(ws, n, s - 1), c)) != ODEHIP_OK) return rc;
@@ -287,13 +262,8 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
     std::vector<float> W((size_t)nout * 7);
     for (int i = 0; i < nout; ++i) {
       const float x = (float)((t_host[j_lo[n] + i] - t0) / (t1 - t0));
-      const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
       for (int s = 0; s < 7; ++s) {
-        const double d1 = s == 0 ? 1.0 : 0.0, d7 = s == 6 ? 1.0 : 0.0, b = bCSol[s], m = bCMid[s];
-        const double A4 = 2.0 * (d7 - d1) - 8.0 * b + 16.0 * m;
-        const double B3 = 5.0 * d1 - 3.0 * d7 + 14.0 * b - 32.0 * m;
-        const double C2 = d7 - 4.0 * d1 - 5.0 * b + 16.0 * m;
-        W[(size_t)i * 7 + s] = h * (float)(x * d1 + x2 * C2 + x3 * B3 + x4 * A4);
+        W[(size_t)i * 7 + s] = h * (float)dp5::dense_weight(s, (double)x);
       }
     }
     for (int s = 7; s >= 1; --s) {  // stage s lives at index s-1
@@ -305,7 +275,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
           cf.push_back(W[(size_t)i * 7 + s - 1]);
         }
       for (int sp = s + 1; sp <= 7; ++sp) {  // Y_{sp} = y0 + h*sum_j beta[sp-2][j] k_{j+1}
-        const float b = (float)bBeta[sp - 2][s - 1];
+        const float b = (float)dp5::kBeta[sp - 2][s - 1];
         if (b != 0.0f) {
           src.push_back(gY[sp - 1]);
           cf.push_back(h * b);

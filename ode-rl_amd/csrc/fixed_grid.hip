@@ -17,23 +17,9 @@
 
 namespace odehip {
 
-struct WgradPair {
-  const float* g;
-  const float* a;
-  float scale;
-  float pad_[3];
-};
-int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
-                 int cin, hipStream_t stream);
-int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
-                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
-int check_stack(const odehip_convstack* f);
-int max_hidden(const odehip_convstack* f);
-int upload_floats(float* dst, const float* src, int n, hipStream_t stream);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 static int n_stages(int method) { return method == ODEHIP_RK4 ? 4 : (method == ODEHIP_MIDPOINT ? 2 : 1); }
 constexpr int kEsplit = 4;
 

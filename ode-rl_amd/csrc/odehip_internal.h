@@ -101,4 +101,57 @@ int launch_bf16(const ConvArgs& a, hipStream_t stream);
 extern int g_debug_flags;
 extern unsigned long long* g_debug_buf;
 
+
+// ---- shared host-side helpers (api.hip, wgrad.hip) ---------------------------------------------------------------------------
+static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+int check_stack(const odehip_convstack* f);
+int max_hidden(const odehip_convstack* f);
+int upload_floats(float* dst, const float* src, int n, hipStream_t stream);  // scalars travel as kernel arguments (async)
+// f(x) with the stage combine fused into the last conv; `hidden` (n_convs-1 buffers) keeps the ReLU outputs for a backward pass
+int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* ping, float* pong, const CombineArgs* cmb,
+              float* plain_dst, const int* skip, hipStream_t stream);
+int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
+                     const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
+
+// one (gradient, activation, weight) triple of the batched weight-gradient kernels (wgrad.hip)
+struct WgradPair {
+  const float* g;  // gradient w.r.t. the layer's output (Q4)
+  const float* a;  // the layer's input (Q4)
+  float scale;     // weight of this evaluation in the sum (1 for discretise-then-optimise; dt*b_s for the adjoint)
+  float pad_[3];
+};
+int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                 int cin, hipStream_t stream);
+int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
+                      int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
+                      hipStream_t stream);
+
+// Dormand-Prince 5(4) tableau as torchdiffeq 0.2.1 holds it (_impl/dopri5.py): beta rows, c_sol (= last beta row, padded),
+// c_error = c_sol - 4th-order weights, c_mid (dense-output midpoint weights)
+namespace dp5 {
+inline constexpr double kBeta[6][6] = {
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+};
+inline constexpr double kCSol[7] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0};
+inline constexpr double kCErr[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                                    -2187.0 / 6784 + 12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60};
+inline constexpr double kCMid[7] = {6025192743.0 / 30085553152.0 / 2, 0, 51252292925.0 / 65400821598.0 / 2,
+                                    -2691868925.0 / 45128329728.0 / 2, 187940372067.0 / 1594534317056.0 / 2,
+                                    -1776094331.0 / 19743644256.0 / 2, 11237099.0 / 235043384.0 / 2};
+// weight of stage s in the dense output at x: value(x) = y0 + h * sum_s dense_weight(s, x) * k_s   (the quartic of _interp_fit)
+inline double dense_weight(int s, double x) {
+  const double d1 = s == 0 ? 1.0 : 0.0, d7 = s == 6 ? 1.0 : 0.0, b = kCSol[s], m = kCMid[s];
+  const double A4 = 2.0 * (d7 - d1) - 8.0 * b + 16.0 * m;
+  const double B3 = 5.0 * d1 - 3.0 * d7 + 14.0 * b - 32.0 * m;
+  const double C2 = d7 - 4.0 * d1 - 5.0 * b + 16.0 * m;
+  return x * d1 + x * x * C2 + x * x * x * B3 + x * x * x * x * A4;
+}
+}  // namespace dp5
+
 }  // namespace odehip

@@ -24,12 +24,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ODEHIP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-struct WgradPair {
-  const float* g;  // GP_e (B,64,16,16) Q4
-  const float* a;  // A_e  (B,64,16,16) Q4
-  float scale;     // weight of this evaluation in the sum (1 for discretise-then-optimise; dt*b_s for the adjoint)
-  float pad_[3];
-};
 
 constexpr int kGPlane = 4096 + 16;       // one quad plane of G in LDS (256 px * 16 B, padded)
 constexpr int kAPlane = 5 * 1024 + 16;   // one quad plane of A in LDS: rows -1..18 (5 DMA pieces), padded

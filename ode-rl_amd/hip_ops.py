@@ -31,12 +31,41 @@ def require_device_tensor(t, name):
         raise TypeError(f"{name} must be float32 (got {t.dtype})")
 
 
+_CANARY = 4096          # guard bytes behind every workspace: a kernel that overruns its carve-out trips check_canaries()
+_guarded = []           # weak references to (full buffer, payload bytes)
+
+
+def alloc_workspace(nbytes, device):
+    """A fresh workspace of `nbytes` with a guard region behind it; returns the payload view (numel() == nbytes)."""
+    import weakref
+    nbytes = max(int(nbytes), 1024)
+    full = torch.empty(nbytes + _CANARY, dtype=torch.uint8, device=device)
+    full[nbytes:].fill_(0xA5)
+    view = full[:nbytes]
+    _guarded.append((weakref.ref(full), nbytes))
+    view._odehip_full = full   # keeps the guard alive as long as the view
+    return view
+
+
+def check_canaries():
+    """Raises if any live workspace's guard bytes were overwritten (tests call this after every GPU test)."""
+    alive = []
+    for ref, nbytes in _guarded:
+        full = ref()
+        if full is None:
+            continue
+        alive.append((ref, nbytes))
+        if not bool((full[nbytes:] == 0xA5).all()):
+            raise RuntimeError(f"a HIP kernel wrote beyond its {nbytes}-byte workspace")
+    _guarded[:] = alive
+
+
 def workspace(key, nbytes, device):
     """Persistent per-shape scratch so that pointers stay stable across calls (graph replay)."""
     k = (key, device)
     buf = _workspaces.get(k)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=device)
+        buf = alloc_workspace(nbytes, device)
         _workspaces[k] = buf
     return buf
 
@@ -278,7 +307,7 @@ def odeint_fixed(stack, method, z0, t, save=False, negate=False):
     m = _lib.METHODS[method]
     nbytes = lib.odehip_odeint_workspace_bytes(ctypes.byref(desc), b, n, m, int(save))
     if save:  # private: it must survive untouched until backward
-        ws = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=z0.device)
+        ws = alloc_workspace(nbytes, z0.device)
     else:
         ws = workspace(("odeint", b, n, m, tuple(desc.channels)), nbytes, z0.device)
     out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
@@ -575,7 +604,7 @@ def odeconvgru_encode_train(enc, inputs, timesteps):
     assert t == len(t64), "Sequence length should be same as time_steps"
     lib = _lib.load()
     nbytes = lib.odehip_encoder_train_workspace_bytes(ctypes.byref(d), t, b)
-    ws = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=inputs.device)   # owned by this call's graph node
+    ws = alloc_workspace(nbytes, inputs.device)   # owned by this call's graph node
     mean = torch.empty((b, d.out_ch, 16, 16), dtype=torch.float32, device=inputs.device)
     std = torch.empty_like(mean)
     tarr = (ctypes.c_double * t)(*t64)

@@ -36,3 +36,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _workspace_guards(request):
+    """After every GPU test: no HIP kernel may have written past the workspace it was given (hip_ops.check_canaries)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and torch.cuda.is_available():
+        from ode_rl_amd import hip_ops
+        torch.cuda.synchronize()
+        hip_ops.check_canaries()

@@ -31,7 +31,8 @@ def main():
     truth = torch.rand(a.batch, T, 1, 64, 64, device=dev)
     ts = torch.arange(2 * T, dtype=torch.float64, device=dev) / (2 * T)
     bd = {"observed_tp": ts[:T], "tp_to_predict": ts[T:]}
-    optim = torch.optim.Adam(m.parameters(), lr=1e-4)
+    from ode_rl_amd.optim import FusedAdam
+    optim = FusedAdam(m.parameters(), lr=1e-4)
 
     def timed(fn, n):
         fn()
