@@ -66,6 +66,8 @@ int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cou
  * bf16 kernel serves; odehip_bf16_weight_bytes(cout, cin) bytes.  transpose_flip as odehip_pack_conv_weight. */
 size_t odehip_bf16_weight_bytes(int cout, int cin);
 int odehip_pack_conv_weight_bf16(const float* w_oihw, void* w_bf16, int cout, int cin, int transpose_flip, void* stream);
+/* the same for the 5x5 convs of the ConvGRU cell (block-major image, cout*cin*25*2 bytes) */
+int odehip_pack_conv_weight_bf16_ks(const float* w_oihw, void* w_bf16, int cout, int cin, int ks, int transpose_flip, void* stream);
 
 int odehip_nchw_to_q4(const float* src_nchw, float* dst_q4, int batch, int channels, void* stream);
 int odehip_q4_to_nchw(const float* src_q4, float* dst_nchw, int batch, int channels, void* stream);
@@ -165,6 +167,8 @@ typedef struct odehip_convgru_cell {
   const float* b_can;
   const float* gn_can_w;
   const float* gn_can_b;
+  const void* w_gates_bf16;    /* optional: odehip_pack_conv_weight_bf16_ks images; non-NULL = bf16 operands, fp32 accumulation */
+  const void* w_can_bf16;      /*           (5x5 cells with input + hidden <= 128 channels)                                   */
 } odehip_convgru_cell;
 
 size_t odehip_convgru_cell_workspace_bytes(const odehip_convgru_cell* c, int batch);
@@ -197,6 +201,7 @@ typedef struct odehip_convgru_cell_bwd {
   const float* w_gates_dh;     /* ... conv_gates.0.weight[:, input:]                                                       */
   const float* w_can_dx;       /* ... conv_can.0.weight[:, :input]                                                         */
   const float* w_can_dh;       /* ... conv_can.0.weight[:, input:]                                                         */
+  const void* bf16[4];         /* optional bf16 images of the same four (odehip_pack_conv_weight_bf16_ks, transpose_flip = 1)  */
 } odehip_convgru_cell_bwd;
 typedef struct odehip_convgru_cell_grads {
   float *w_gates, *b_gates, *gn_gates_w, *gn_gates_b, *w_can, *b_can, *gn_can_w, *gn_can_b;
@@ -217,6 +222,7 @@ typedef struct odehip_encoder_bwd {
   const float* w_can_dh;       /* ... conv_can.0.weight[:, input:]                                                         */
   const float* w_head0_t;      /* ... transform_z0.0.weight, transform_z0.2.weight                                         */
   const float* w_head1_t;
+  const void* bf16[4];         /* optional bf16 images of w_gates_dx, w_gates_dh, w_can_dx, w_can_dh                          */
 } odehip_encoder_bwd;
 
 typedef struct odehip_encoder_grads {  /* outputs, each shaped like its parameter (conv weights OIHW) */

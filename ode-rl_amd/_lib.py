@@ -44,7 +44,8 @@ class ConvGRUCellDesc(ctypes.Structure):
     _fields_ = [("input", ctypes.c_int), ("hidden", ctypes.c_int), ("ks", ctypes.c_int),
                 ("w_gates", ctypes.c_void_p), ("b_gates", ctypes.c_void_p), ("gn_gates_w", ctypes.c_void_p),
                 ("gn_gates_b", ctypes.c_void_p), ("w_can", ctypes.c_void_p), ("b_can", ctypes.c_void_p),
-                ("gn_can_w", ctypes.c_void_p), ("gn_can_b", ctypes.c_void_p)]
+                ("gn_can_w", ctypes.c_void_p), ("gn_can_b", ctypes.c_void_p),
+                ("w_gates_bf16", ctypes.c_void_p), ("w_can_bf16", ctypes.c_void_p)]
 
 
 class EncoderDesc(ctypes.Structure):
@@ -55,7 +56,7 @@ class EncoderDesc(ctypes.Structure):
 
 class ConvGRUCellBwd(ctypes.Structure):
     _fields_ = [("w_gates_dx", ctypes.c_void_p), ("w_gates_dh", ctypes.c_void_p), ("w_can_dx", ctypes.c_void_p),
-                ("w_can_dh", ctypes.c_void_p)]
+                ("w_can_dh", ctypes.c_void_p), ("bf16", ctypes.c_void_p * 4)]
 
 
 class ConvGRUCellGrads(ctypes.Structure):
@@ -67,7 +68,7 @@ class ConvGRUCellGrads(ctypes.Structure):
 class EncoderBwd(ctypes.Structure):
     _fields_ = [("f_dgrad", ConvStack), ("w_gates_dx", ctypes.c_void_p), ("w_gates_dh", ctypes.c_void_p),
                 ("w_can_dx", ctypes.c_void_p), ("w_can_dh", ctypes.c_void_p), ("w_head0_t", ctypes.c_void_p),
-                ("w_head1_t", ctypes.c_void_p)]
+                ("w_head1_t", ctypes.c_void_p), ("bf16", ctypes.c_void_p * 4)]
 
 
 class EncoderGrads(ctypes.Structure):
@@ -98,6 +99,8 @@ SIGNATURES = {
                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                         ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_pack_conv_weight_bf16_ks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
     "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),

@@ -419,6 +419,10 @@ int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
   }
   if (ks == 5) {
     ODEHIP_REQUIRE(a.qin % 2 == 0, "conv_q4: 5x5 needs cin %% 8 == 0 (got %d)", a.qin * 4);
+    if (a.w_bf16) {
+      const int rb = launch_bf16_5x5(a, stream);
+      if (rb != 1) return rb;
+    }
     return launch_ring<5, 1, 4>(a, stream);
   }
   if (ks == 1) {

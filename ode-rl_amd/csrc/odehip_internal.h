@@ -98,6 +98,7 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_bf16(const ConvArgs& a, hipStream_t stream);
+int launch_bf16_5x5(const ConvArgs& a, hipStream_t stream);
 extern int g_debug_flags;
 extern unsigned long long* g_debug_buf;
 

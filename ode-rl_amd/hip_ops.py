@@ -175,6 +175,22 @@ def pack_conv_weight_bf16(w, transpose_flip=False):
     return out
 
 
+def pack_conv_weight_bf16_ks(w, transpose_flip=False):
+    """(Cout,Cin,5,5) fp32 -> block-major bf16 image of the 5x5 bf16 ring kernel."""
+    require_device_tensor(w, "weight")
+    w = w.detach().contiguous()
+    co, ci, k, k2 = w.shape
+    if transpose_flip:
+        co, ci = ci, co
+    out = torch.empty(co * ci * k * k2, dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.load().odehip_pack_conv_weight_bf16_ks(_ptr(w), _ptr(out), co, ci, k, int(bool(transpose_flip)), _stream()))
+    return out
+
+
+def _bf16_cell_ok(cell_input, hidden, ks):
+    return ks == 5 and cell_input % 16 == 0 and hidden % 32 == 0 and cell_input + hidden <= 128
+
+
 def _bf16_ok(cin, cout, ks):
     return ks == 3 and cin % 16 == 0 and cin <= 128 and cin // 16 in (1, 2, 4, 8) and cout % 32 == 0
 
@@ -452,12 +468,13 @@ def odeint_adjoint_dopri5_backward(stack, t, y_traj, grad_out, rtol, atol, max_a
 
 
 class PackedCell:
-    """Packed parameters of a ConvGRUCell (conv_gates / conv_can Sequentials), refreshed on parameter change."""
+    """Packed parameters of a ConvGRUCell (conv_gates / conv_can Sequentials), refreshed on parameter change; one cache entry
+    per compute dtype (the bf16 entry adds the bf16 weight images of the two 5x5 convs)."""
 
     def __init__(self, cell):
         self.cell = cell
-        self._stamp = None
-        self._keep = None
+        self._cache = {}
+        self._stamp = None     # identity of the entry returned last (keys the derived caches)
         self.desc = None
 
     def _params(self):
@@ -465,11 +482,14 @@ class PackedCell:
         return [c.conv_gates[0].weight, c.conv_gates[0].bias, c.conv_gates[1].weight, c.conv_gates[1].bias,
                 c.conv_can[0].weight, c.conv_can[0].bias, c.conv_can[1].weight, c.conv_can[1].bias]
 
-    def refresh(self):
+    def refresh(self, mode=None):
+        mode = mode or current_compute_dtype()
         ps = self._params()
-        stamp = tuple((p.data_ptr(), p._version) for p in ps)
-        if stamp == self._stamp:
-            return self.desc
+        stamp = (mode,) + tuple((p.data_ptr(), p._version) for p in ps)
+        ent = self._cache.get(mode)
+        if ent is not None and ent[0] == stamp:
+            self._stamp, self.desc = ent[0], ent[1]
+            return ent[1]
         for p in ps:
             require_device_tensor(p, "ConvGRUCell parameter")
         c = self.cell
@@ -480,12 +500,30 @@ class PackedCell:
             raise ValueError("the HIP ConvGRU needs GroupNorm groups of 32 channels (hidden_dim multiple of 32)")
         keep = [pack_conv_weight(ps[0]), ps[1].detach().contiguous(), ps[2].detach().contiguous(), ps[3].detach().contiguous(),
                 pack_conv_weight(ps[4]), ps[5].detach().contiguous(), ps[6].detach().contiguous(), ps[7].detach().contiguous()]
+        bf = [None, None]
+        if mode == "bf16" and _bf16_cell_ok(c.input_channels, c.hidden_dim, ks):
+            bf = [pack_conv_weight_bf16_ks(ps[0]), pack_conv_weight_bf16_ks(ps[4])]
         d = _lib.ConvGRUCellDesc(input=c.input_channels, hidden=c.hidden_dim, ks=ks,
                                  w_gates=keep[0].data_ptr(), b_gates=keep[1].data_ptr(), gn_gates_w=keep[2].data_ptr(),
                                  gn_gates_b=keep[3].data_ptr(), w_can=keep[4].data_ptr(), b_can=keep[5].data_ptr(),
-                                 gn_can_w=keep[6].data_ptr(), gn_can_b=keep[7].data_ptr())
-        self._keep, self.desc, self._stamp = keep, d, stamp
+                                 gn_can_w=keep[6].data_ptr(), gn_can_b=keep[7].data_ptr(),
+                                 w_gates_bf16=bf[0].data_ptr() if bf[0] is not None else None,
+                                 w_can_bf16=bf[1].data_ptr() if bf[1] is not None else None)
+        self._cache[mode] = (stamp, d, keep, bf)
+        self._stamp, self.desc = stamp, d
         return d
+
+
+def _cell_bwd_packs(cell, d, mode):
+    """Transposed + flipped slices of the two 5x5 weights (frame half, state half), fp32 images and, in bf16 mode, bf16 ones."""
+    i = d.input
+    wg, wc = cell.conv_gates[0].weight.detach(), cell.conv_can[0].weight.detach()
+    slices = [wg[:, :i], wg[:, i:], wc[:, :i], wc[:, i:]]
+    keep = [pack_conv_weight(w, True) for w in slices]
+    bf = [None] * 4
+    if mode == "bf16" and d.ks == 5 and all(w.shape[0] <= 128 and w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0 for w in slices):
+        bf = [pack_conv_weight_bf16_ks(w, True) for w in slices]
+    return keep, bf
 
 
 def convgru_cell_forward(packed_cell, x, h):
@@ -510,13 +548,12 @@ def convgru_cell_backward(packed_cell, x, h, grad_h_next):
         require_device_tensor(t_, n_)
     d = packed_cell.refresh()
     cached = getattr(packed_cell, "_bwd", None)
-    if cached is None or cached[0] is not packed_cell._stamp:
-        cell, i = packed_cell.cell, d.input
-        wg, wc = cell.conv_gates[0].weight.detach(), cell.conv_can[0].weight.detach()
-        keep = [pack_conv_weight(wg[:, :i], True), pack_conv_weight(wg[:, i:], True), pack_conv_weight(wc[:, :i], True),
-                pack_conv_weight(wc[:, i:], True)]
+    if cached is None or cached[0] != packed_cell._stamp:
+        keep, bf = _cell_bwd_packs(packed_cell.cell, d, current_compute_dtype())
         bw = _lib.ConvGRUCellBwd(*[k.data_ptr() for k in keep])
-        cached = packed_cell._bwd = (packed_cell._stamp, bw, keep)
+        for j in range(4):
+            bw.bf16[j] = bf[j].data_ptr() if bf[j] is not None else None
+        cached = packed_cell._bwd = (packed_cell._stamp, bw, keep, bf)
     bw = cached[1]
     x, h, grad_h_next = x.contiguous(), h.contiguous(), grad_h_next.contiguous()
     b = x.shape[0]
@@ -580,14 +617,14 @@ def _encoder_bwd_desc(enc):
     cached = getattr(enc, "_bwd", None)
     if cached is not None and cached[0] is stamp:
         return cached[1]
-    cell = enc.packed_cell.cell
-    i = d.cell.input
-    wg, wc = cell.conv_gates[0].weight.detach(), cell.conv_can[0].weight.detach()
-    keep = [pack_conv_weight(wg[:, :i], True), pack_conv_weight(wg[:, i:], True), pack_conv_weight(wc[:, :i], True),
-            pack_conv_weight(wc[:, i:], True), pack_conv_weight(enc.head[0].weight, True), pack_conv_weight(enc.head[2].weight, True)]
+    keep, bf = _cell_bwd_packs(enc.packed_cell.cell, d.cell, current_compute_dtype())
+    keep += [pack_conv_weight(enc.head[0].weight, True), pack_conv_weight(enc.head[2].weight, True)]
     b = _lib.EncoderBwd()
     b.f_dgrad = enc.f_stack.dgrad_desc()
     b.w_gates_dx, b.w_gates_dh, b.w_can_dx, b.w_can_dh, b.w_head0_t, b.w_head1_t = (k.data_ptr() for k in keep)
+    for j in range(4):
+        b.bf16[j] = bf[j].data_ptr() if bf[j] is not None else None
+    keep = keep + bf
     enc._bwd = (stamp, b, keep)
     return b
 

@@ -70,7 +70,7 @@ def split_convnet_state(sd, prefix=""):
 
 
 # --------------------------------------------------------------------------- ConvGRU cell
-def convgru_cell(x, h, p):
+def convgru_cell(x, h, p, compute_dtype="f32"):
     """One step of `modules/ConvGRUCell.py:72-82`.
 
     p: dict with conv_gates.0.{weight,bias}, conv_gates.1.{weight,bias} (GroupNorm affine),
@@ -79,17 +79,19 @@ def convgru_cell(x, h, p):
     """
     hid = h.shape[1]
     pad = p["conv_gates.0.weight"].shape[-1] // 2
-    g = F.conv2d(torch.cat((x, h), 1), p["conv_gates.0.weight"], p["conv_gates.0.bias"], padding=pad)
+    def conv(inp, w, b):   # compute_dtype="bf16": the HIP bf16 path's arithmetic (bf16 operands, fp32 accumulation)
+        return _MixedConv.apply(inp, w, b) if compute_dtype == "bf16" else F.conv2d(inp, w, b, padding=pad)
+    g = conv(torch.cat((x, h), 1), p["conv_gates.0.weight"], p["conv_gates.0.bias"])
     g = F.group_norm(g, 2 * hid // 32, p["conv_gates.1.weight"], p["conv_gates.1.bias"], eps=1e-5)
     zg, rg = torch.split(g, hid, dim=1)
     z, r = torch.sigmoid(zg), torch.sigmoid(rg)
-    c = F.conv2d(torch.cat((x, r * h), 1), p["conv_can.0.weight"], p["conv_can.0.bias"], padding=pad)
+    c = conv(torch.cat((x, r * h), 1), p["conv_can.0.weight"], p["conv_can.0.bias"])
     c = torch.tanh(F.group_norm(c, hid // 32, p["conv_can.1.weight"], p["conv_can.1.bias"], eps=1e-5))
     return (1 - z) * h + z * c
 
 
 # --------------------------------------------------------------------------- encoder loop
-def ode_convgru_encode(inputs, timesteps, f_enc, cell_params, head_params):
+def ode_convgru_encode(inputs, timesteps, f_enc, cell_params, head_params, compute_dtype="f32"):
     """`modules/ODEConvGRUCell.py:32-78`: reverse-time explicit-Euler + ConvGRU loop, then the
     1x1 -> ReLU -> 1x1 head, split into (mean_z0, |std_z0|).
 
@@ -104,7 +106,7 @@ def ode_convgru_encode(inputs, timesteps, f_enc, cell_params, head_params):
         inc = f_enc(prev_t, prev) * (t_i - prev_t)
         assert not torch.isnan(inc).any()
         ode_sol = prev + inc
-        yi = convgru_cell(inputs[i], ode_sol, cell_params)
+        yi = convgru_cell(inputs[i], ode_sol, cell_params, compute_dtype)
         prev = yi
         prev_t, t_i = timesteps[i], timesteps[i - 1]
         ys.append(yi)

@@ -18,8 +18,12 @@ def main():
     p.add_argument("--frames", type=int, default=10)
     p.add_argument("--method", default="rk4")
     p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the hot-path convs")
     a = p.parse_args()
+    import ode_rl_amd
     from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
+    if a.dtype == "bf16":
+        ode_rl_amd.set_compute_dtype("bf16")
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     opt = argparse.Namespace(resolution=64, n_downs=2, conv_encoder_out_ch=64, in_channels=1, n_ode_layers=3,
@@ -53,7 +57,7 @@ def main():
         loss.backward()
         optim.step()
 
-    res = {"batch": a.batch, "frames_in": T, "frames_out": T, "method": a.method}
+    res = {"batch": a.batch, "frames_in": T, "frames_out": T, "method": a.method, "dtype": a.dtype}
     res["forward_ms"] = timed(fwd, a.steps)
     res["train_step_ms"] = timed(train, a.steps)
     # parts of the forward
