@@ -66,6 +66,10 @@ int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cou
  * bf16 kernel serves; odehip_bf16_weight_bytes(cout, cin) bytes.  transpose_flip as odehip_pack_conv_weight. */
 size_t odehip_bf16_weight_bytes(int cout, int cin);
 int odehip_pack_conv_weight_bf16(const float* w_oihw, void* w_bf16, int cout, int cin, int transpose_flip, void* stream);
+/* fused image of a 64 -> 64 3x3 stack: call once per layer with its position `exec_index` in execution order (forward: the
+ * layer index; input-gradient chain: n_convs-1-layer with transpose_flip = 1); odehip_fused_bf16_weight_bytes(n_layers) bytes */
+size_t odehip_fused_bf16_weight_bytes(int n_layers);
+int odehip_pack_convstack_fused_bf16(const float* w_oihw, void* w_fused, int exec_index, int transpose_flip, void* stream);
 /* the same for the 5x5 convs of the ConvGRU cell (block-major image, cout*cin*25*2 bytes) */
 int odehip_pack_conv_weight_bf16_ks(const float* w_oihw, void* w_bf16, int cout, int cin, int ks, int transpose_flip, void* stream);
 
@@ -87,6 +91,10 @@ typedef struct odehip_conv_desc {
 } odehip_conv_desc;
 
 int odehip_conv_q4(const odehip_conv_desc* d, void* stream);
+/* diagnostic: n back-to-back evaluations of f on Q4 tensors; scratch holds 2 hidden activations (tools/fused_microbench.py) */
+struct odehip_convstack;
+int odehip_debug_repeat_f(const struct odehip_convstack* f, const float* x_q4, float* out_q4, float* scratch, int batch, int n,
+                          void* stream);
 /* diagnostic: n back-to-back launches of the same layer (tools/conv_microbench.py) */
 int odehip_debug_repeat_conv(const odehip_conv_desc* d, int n, void* stream);
 
@@ -100,6 +108,8 @@ typedef struct odehip_convstack {
   const float* w_wino[ODEHIP_MAX_LAYERS];  /* optional Winograd forms (3x3 layers), NULL entries run the direct kernel */
   const void* w_bf16[ODEHIP_MAX_LAYERS];   /* optional bf16 forms: a non-NULL entry runs that layer with bf16 operands and fp32
                                               accumulation (BASELINE.json configs[4]); state and stage combines stay fp32 */
+  const void* w_fused;                     /* optional (odehip_pack_convstack_fused_bf16): when every layer is 3x3, 64 -> 64, the
+                                              whole stack runs as ONE bf16 launch, one workgroup per sample (fstack_bf16.hip)   */
   const float* bias[ODEHIP_MAX_LAYERS];
   int final_tanh;                        /* final_act=True appends Tanh (helpers/utils.py:179-181)  */
 } odehip_convstack;

@@ -35,6 +35,7 @@ class ConvStack(ctypes.Structure):
         ("w_packed", ctypes.c_void_p * MAX_LAYERS),
         ("w_wino", ctypes.c_void_p * MAX_LAYERS),
         ("w_bf16", ctypes.c_void_p * MAX_LAYERS),
+        ("w_fused", ctypes.c_void_p),
         ("bias", ctypes.c_void_p * MAX_LAYERS),
         ("final_tanh", ctypes.c_int),
     ]
@@ -99,8 +100,12 @@ SIGNATURES = {
                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                         ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_fused_bf16_weight_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "odehip_pack_convstack_fused_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_pack_conv_weight_bf16_ks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_int, ctypes.c_void_p]),
+    "odehip_debug_repeat_f": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
     "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),

@@ -208,29 +208,13 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
     for (int l = 0; l < NH; ++l) hidv[l] = L.hidden(ws, slot, s, l);
     int r = enqueue_f_saving(f, Y, batch, hidv, ping, pong, &cy, nullptr, nullptr, stream);
     if (r != ODEHIP_OK) return r;
-    for (int l = NL - 1; l >= 0; --l) {
-      ConvArgs a;
-      memset(&a, 0, sizeof(a));
-      a.src1 = L.gp(ws, slot, s, l);
-      a.q1 = a.qin = f->channels[l + 1] / 4;
-      a.qout = f->channels[l] / 4;
-      a.w_packed = f_dgrad->w_packed[l];
-      a.w_wino = f_dgrad->w_wino[l];
-      a.w_bf16 = f_dgrad->w_bf16[l];
-      a.batch = batch;
-      if (l > 0) {
-        a.combine = 2;
-        a.bwd.mask_src = L.hidden(ws, slot, s, l - 1);
-        a.bwd.sc_c = 1.0f;
-        a.dst = L.gp(ws, slot, s, l - 1);
-      } else {
-        a.combine = 1;
-        a.cmb = ca;
-      }
-      r = launch_conv(a, f->ks, stream);
-      if (r != ODEHIP_OK) return r;
-    }
-    return ODEHIP_OK;
+    float* gpv[ODEHIP_MAX_LAYERS];
+    for (int l = 0; l < NL; ++l) gpv[l] = L.gp(ws, slot, s, l);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.combine = 1;
+    a.cmb = ca;
+    return enqueue_dgrad_chain(f, f_dgrad, batch, gpv, hidv, a, stream);
   };
   auto sumsq = [&](int j, const float* a, const float* b, const float* y) {
     hipLaunchKernelGGL(adj_sumsq_kernel, dim3(256), dim3(256), 0, stream, a, b, y, atol, rtol, n4, L.part(ws, j));

@@ -46,6 +46,11 @@ int check_stack(const odehip_convstack* f) {
                    "convstack: channels[%d] = %d must be a positive multiple of 32", i, f->channels[i]);
   for (int i = 0; i < f->n_convs; ++i)
     ODEHIP_REQUIRE(f->w_packed[i] && f->bias[i], "convstack: layer %d has null weights/bias", i);
+  if (f->w_fused) {
+    ODEHIP_REQUIRE(f->ks == 3, "convstack: the fused bf16 image needs 3x3 layers");
+    for (int i = 0; i <= f->n_convs; ++i)
+      ODEHIP_REQUIRE(f->channels[i] == 64, "convstack: the fused bf16 image needs 64-channel layers (channels[%d] = %d)", i, f->channels[i]);
+  }
   return ODEHIP_OK;
 }
 
@@ -85,6 +90,27 @@ int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* pi
 
 int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
                      const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream) {
+  if (f->w_fused) {  // bf16, every layer 64 -> 64: one launch for the whole stack, one workgroup per sample
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.x = x_q4;
+    fa.w_fused = f->w_fused;
+    fa.n_layers = f->n_convs;
+    for (int l = 0; l < f->n_convs; ++l) {
+      fa.bias[l] = f->bias[l];
+      if (l < f->n_convs - 1) fa.store[l] = hidden ? hidden[l] : nullptr;
+    }
+    fa.last.qout = 16;
+    fa.last.batch = batch;
+    fa.last.skip = skip;
+    if (cmb) {
+      fa.last.combine = 1;
+      fa.last.cmb = *cmb;
+    } else {
+      fa.last.dst = plain_dst;
+    }
+    return launch_fstack_bf16(fa, batch, stream);
+  }
   const float* cur = x_q4;
   for (int l = 0; l < f->n_convs; ++l) {
     const bool last = (l == f->n_convs - 1);
@@ -113,6 +139,51 @@ int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, fl
     }
     int rc = launch_conv(a, f->ks, stream);
     if (rc != ODEHIP_OK) return rc;
+  }
+  return ODEHIP_OK;
+}
+
+int enqueue_dgrad_chain(const odehip_convstack* f, const odehip_convstack* fd, int batch, float* const* gp,
+                        const float* const* hidden, const ConvArgs& last, hipStream_t stream) {
+  const int NL = f->n_convs;
+  if (fd->w_fused) {  // bf16, 64-channel stack: the whole chain in one launch (layers in execution order NL-1 .. 0)
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.x = gp[NL - 1];
+    fa.w_fused = fd->w_fused;
+    fa.n_layers = NL;
+    for (int e = 0; e < NL - 1; ++e) {
+      const int l = NL - 1 - e;
+      fa.store[e] = gp[l - 1];
+      fa.mask[e] = hidden[l - 1];
+    }
+    fa.last = last;
+    fa.last.qout = 16;
+    fa.last.batch = batch;
+    return launch_fstack_bf16(fa, batch, stream);
+  }
+  for (int l = NL - 1; l >= 0; --l) {
+    ConvArgs a;
+    if (l > 0) {
+      memset(&a, 0, sizeof(a));
+      a.combine = 2;
+      a.bwd.mask_src = hidden[l - 1];  // ReLU output that fed conv l
+      a.bwd.sc_c = 1.0f;
+      a.dst = gp[l - 1];
+    } else {
+      a = last;
+    }
+    a.src1 = gp[l];  // gradient w.r.t. the output of conv l
+    a.src2 = nullptr;
+    a.q1 = a.qin = f->channels[l + 1] / 4;
+    a.qout = f->channels[l] / 4;
+    a.w_packed = fd->w_packed[l];
+    a.w_wino = fd->w_wino[l];
+    a.w_bf16 = fd->w_bf16[l];
+    a.bias = nullptr;
+    a.batch = batch;
+    int r = launch_conv(a, f->ks, stream);
+    if (r != ODEHIP_OK) return r;
   }
   return ODEHIP_OK;
 }
@@ -159,6 +230,19 @@ extern "C" int odehip_debug_repeat_conv(const odehip_conv_desc* d, int n, void* 
 }
 
 // workspace of f(y): [x_q4 | ping | pong | out_q4]
+// diagnostic: n back-to-back evaluations of f on Q4 tensors (tools/fused_microbench.py); scratch = 2 hidden-sized buffers
+extern "C" int odehip_debug_repeat_f(const odehip_convstack* f, const float* x_q4, float* out_q4, float* scratch, int batch, int n,
+                                     void* stream) {
+  int rc = check_stack(f);
+  if (rc != ODEHIP_OK) return rc;
+  const size_t hid = (size_t)batch * max_hidden(f) * kPix;
+  for (int i = 0; i < n; ++i) {
+    rc = enqueue_f(f, x_q4, batch, scratch, scratch + hid, nullptr, out_q4, nullptr, (hipStream_t)stream);
+    if (rc != ODEHIP_OK) return rc;
+  }
+  return ODEHIP_OK;
+}
+
 extern "C" size_t odehip_convstack_workspace_bytes(const odehip_convstack* f, int batch) {
   if (!f || batch <= 0) return 0;
   const size_t hid = align_up(state_bytes(batch, max_hidden(f)), 256);

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_ring_kernel(const ConvArgs a
   for (int cb = 0; cb < ncb; ++cb) {
     // blocks cb (and cb+1 if issued) are in flight behind the activation loads, which have been consumed above
     if (cb + 1 < ncb) wait_vmcnt<G>(); else wait_vmcnt<0>();
-    __syncthreads();  // block cb landed for every wave; every wave is done with block cb-1 (its stage is free for cb+2)
+    // raw barrier (a __syncthreads() would drain vmcnt to 0 and serialise the ring); lgkmcnt(0): this wave's staging writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // block cb landed for every wave; every wave is done with block cb-1 (its stage is free for cb+2)
     if (cb + 2 < ncb) issue(cb + 2);
     const char* abase = wl + (cb % NSTAGE) * STAGE + lane * 16;
 #pragma unroll

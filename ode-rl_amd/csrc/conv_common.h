@@ -158,7 +158,8 @@ __device__ __forceinline__ f32x16 bias_init(const float* bias, int ct, int kq) {
 }
 
 // ---- epilogue: lane (pixel i32, half kq) holds channel quads 2g+kq of this 32-channel tile
-__device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, int b, int ct, int P, int kq, int wave) {
+// part_idx >= 0 overrides the slot of this wave's error-norm partial (kernels whose grid is not (tile, sample))
+__device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, int b, int ct, int P, int kq, int wave, int part_idx = -1) {
   if (!a.combine) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -247,7 +248,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
   if (m.err_partials) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-    if ((threadIdx.x & 63) == 0) m.err_partials[(blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave] = esum;
+    if ((threadIdx.x & 63) == 0) m.err_partials[part_idx >= 0 ? part_idx : (int)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + wave] = esum;
   }
 }
 

@@ -470,31 +470,21 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
     w.tgt[0].srcA = gh_ode;
     if ((rc = conv_bwd(g_gates, 2 * C, C, ks, eb->w_gates_dh, 3, &w, nullptr, eb->bf16[1])) != ODEHIP_OK) return rc;
     // h_ode = h + dt f(h):  gh = seed + dt J_f(h)^T seed
-    for (int l = NL - 1; l >= 0; --l) {
+    {
+      float* gpv[ODEHIP_MAX_LAYERS];
+      const float* hv[ODEHIP_MAX_LAYERS];
+      for (int l = 0; l < NL; ++l) gpv[l] = L.gp(ws, idx, l);
+      for (int l = 0; l + 1 < NL; ++l) hv[l] = L.hidden(ws, idx, l);
       ConvArgs a;
       memset(&a, 0, sizeof(a));
-      a.src1 = L.gp(ws, idx, l);
-      a.q1 = a.qin = e->f_enc.channels[l + 1] / 4;
-      a.qout = e->f_enc.channels[l] / 4;
-      a.w_packed = eb->f_dgrad.w_packed[l];
-      a.w_wino = eb->f_dgrad.w_wino[l];
-      a.w_bf16 = eb->f_dgrad.w_bf16[l];
-      a.batch = batch;
-      if (l > 0) {
-        a.combine = 2;
-        a.bwd.mask_src = L.hidden(ws, idx, l - 1);
-        a.bwd.sc_c = 1.0f;
-        a.dst = L.gp(ws, idx, l - 1);
-      } else {
-        a.combine = 3;
-        a.bwd.n_targets = 1;
-        a.bwd.h_ptr = dts + idx;
-        a.bwd.tgt[0].out = gh_next;
-        a.bwd.tgt[0].srcA = L.gp(ws, idx, NH);
-        a.bwd.tgt[0].a_c = 1.0f;
-        a.bwd.tgt[0].g_h = 1.0f;
-      }
-      if ((rc = launch_conv(a, e->f_enc.ks, stream)) != ODEHIP_OK) return rc;
+      a.combine = 3;
+      a.bwd.n_targets = 1;
+      a.bwd.h_ptr = dts + idx;
+      a.bwd.tgt[0].out = gh_next;
+      a.bwd.tgt[0].srcA = L.gp(ws, idx, NH);
+      a.bwd.tgt[0].a_c = 1.0f;
+      a.bwd.tgt[0].g_h = 1.0f;
+      if ((rc = enqueue_dgrad_chain(&e->f_enc, &eb->f_dgrad, batch, gpv, hv, a, stream)) != ODEHIP_OK) return rc;
     }
     float* t = gh; gh = gh_next; gh_next = t;
   }

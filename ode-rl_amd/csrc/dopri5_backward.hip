@@ -223,29 +223,15 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
 
   // ---- 2. reverse sweep ------------------------------------------------------------------------------------------------------
   auto chain = [&](int n, int s, const BwdArgs& last) -> int {  // J_f(Y)^T seed, seed = gp[n][s][NH]
-    for (int l = NL - 1; l >= 0; --l) {
-      ConvArgs a;
-      memset(&a, 0, sizeof(a));
-      a.src1 = L.gp(ws, n, s, l);
-      a.q1 = a.qin = f->channels[l + 1] / 4;
-      a.qout = f->channels[l] / 4;
-      a.w_packed = f_dgrad->w_packed[l];
-      a.w_wino = f_dgrad->w_wino[l];
-      a.w_bf16 = f_dgrad->w_bf16[l];
-      a.batch = batch;
-      if (l > 0) {
-        a.combine = 2;
-        a.bwd.mask_src = L.hidden(ws, n, s, l - 1);
-        a.bwd.sc_c = 1.0f;
-        a.dst = L.gp(ws, n, s, l - 1);
-      } else {
-        a.combine = 3;
-        a.bwd = last;
-      }
-      int r = launch_conv(a, f->ks, stream);
-      if (r != ODEHIP_OK) return r;
-    }
-    return ODEHIP_OK;
+    float* gpv[ODEHIP_MAX_LAYERS];
+    const float* hv[ODEHIP_MAX_LAYERS];
+    for (int l = 0; l < NL; ++l) gpv[l] = L.gp(ws, n, s, l);
+    for (int l = 0; l + 1 < NL; ++l) hv[l] = L.hidden(ws, n, s, l);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.combine = 3;
+    a.bwd = last;
+    return enqueue_dgrad_chain(f, f_dgrad, batch, gpv, hv, a, stream);
   };
   float* gy = L.p(ws, L.off_gy);                 // gradient w.r.t. the state at the end of the step being processed
   float* gy_new = L.p(ws, L.off_gy + L.st);

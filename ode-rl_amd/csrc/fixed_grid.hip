@@ -287,29 +287,15 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
 
   // dgrad chain of evaluation (n, s): GP[n][s][NH] (gradient w.r.t. k) -> ... -> gx, consumed by `targets`
   auto chain = [&](int n, int s, const BwdArgs& last) -> int {
-    for (int l = NL - 1; l >= 0; --l) {
-      ConvArgs a;
-      memset(&a, 0, sizeof(a));
-      a.src1 = L.gp(ws, n, s, l);          // gradient w.r.t. the output of conv l
-      a.q1 = a.qin = f->channels[l + 1] / 4;
-      a.qout = f->channels[l] / 4;
-      a.w_packed = f_dgrad->w_packed[l];
-      a.w_wino = f_dgrad->w_wino[l];
-      a.w_bf16 = f_dgrad->w_bf16[l];
-      a.batch = batch;
-      if (l > 0) {
-        a.combine = 2;
-        a.bwd.mask_src = L.hidden(ws, n, s, l - 1);  // ReLU output that fed conv l
-        a.bwd.sc_c = 1.0f;
-        a.dst = L.gp(ws, n, s, l - 1);
-      } else {
-        a.combine = 3;
-        a.bwd = last;
-      }
-      int r = launch_conv(a, f->ks, stream);
-      if (r != ODEHIP_OK) return r;
-    }
-    return ODEHIP_OK;
+    float* gpv[ODEHIP_MAX_LAYERS];
+    const float* hv[ODEHIP_MAX_LAYERS];
+    for (int l = 0; l < NL; ++l) gpv[l] = L.gp(ws, n, s, l);
+    for (int l = 0; l + 1 < NL; ++l) hv[l] = L.hidden(ws, n, s, l);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.combine = 3;
+    a.bwd = last;
+    return enqueue_dgrad_chain(f, f_dgrad, batch, gpv, hv, a, stream);
   };
   auto tgt = [](float* out, const float* sa, float a_c, float a_h, const float* sb, float b_c, float b_h, float g_c, float g_h) {
     BwdTarget t;
@@ -453,29 +439,15 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
     return enqueue_f_saving(f, x, batch, hidv, ping, pong, &c, nullptr, nullptr, stream);
   };
   auto chain = [&](int n, int s, const BwdArgs& last) -> int {  // K^a = J_f(Y_s)^T A_s, A_s = GP[n][s][NH]
-    for (int l = NL - 1; l >= 0; --l) {
-      ConvArgs a;
-      memset(&a, 0, sizeof(a));
-      a.src1 = L.gp(ws, n, s, l);
-      a.q1 = a.qin = f->channels[l + 1] / 4;
-      a.qout = f->channels[l] / 4;
-      a.w_packed = f_dgrad->w_packed[l];
-      a.w_wino = f_dgrad->w_wino[l];
-      a.w_bf16 = f_dgrad->w_bf16[l];
-      a.batch = batch;
-      if (l > 0) {
-        a.combine = 2;
-        a.bwd.mask_src = L.hidden(ws, n, s, l - 1);
-        a.bwd.sc_c = 1.0f;
-        a.dst = L.gp(ws, n, s, l - 1);
-      } else {
-        a.combine = 3;
-        a.bwd = last;
-      }
-      int r = launch_conv(a, f->ks, stream);
-      if (r != ODEHIP_OK) return r;
-    }
-    return ODEHIP_OK;
+    float* gpv[ODEHIP_MAX_LAYERS];
+    const float* hv[ODEHIP_MAX_LAYERS];
+    for (int l = 0; l < NL; ++l) gpv[l] = L.gp(ws, n, s, l);
+    for (int l = 0; l + 1 < NL; ++l) hv[l] = L.hidden(ws, n, s, l);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.combine = 3;
+    a.bwd = last;
+    return enqueue_dgrad_chain(f, f_dgrad, batch, gpv, hv, a, stream);
   };
   auto tgt = [](float* out, const float* sa, float a_c, const float* sb, float b_c, float g_h) {
     BwdTarget t;

@@ -1,0 +1,202 @@
+// fstack_bf16.hip -- a whole evaluation of the dynamics f (every conv3x3 + ReLU of create_convnet, helpers/utils.py:158-183,
+// plus the Runge-Kutta stage combine of the last layer) in ONE launch, bf16 operands / fp32 accumulation (BASELINE.json
+// configs[4]).  One workgroup = one sample: with bf16 on the matrix cores a 64-channel layer of one 16x16 map is 2.2 us of MFMA
+// on one CU, so the five layers of f need no other workgroup -- and therefore no launch boundary and no trip through HBM between
+// layers: the hidden activations live in LDS as bf16 ([18][18][64] tiles with zero borders, ping-pong), the weights of all
+// layers stream through a 6-stage LDS ring, one tap (8 KiB: 64 co x 64 ci) per stage, counted s_waitcnt + one barrier per tap.
+//   wave w (8 waves, two per SIMD) owns image rows 2w, 2w+1 (32 pixels) and both 32-channel halves: 8 MFMAs
+//   (v_mfma_f32_32x32x16_bf16) per tap, the B operand shared by the two halves; 360 MFMAs per wave per 5-layer f.  (Four waves
+//   with twice the tile halve the weight-fragment reads but measured slower: with one wave per SIMD nothing hides the code
+//   around the per-tap barrier.)  Measured: 5.3 us per layer + 5 us per launch, of which 2.5 us per layer remain with the MFMAs
+//   and the weight DMA switched off -- the per-tap wait/barrier/issue sequence, not the matrix core, is the cost to attack next.
+// The same kernel runs the input-gradient chain of the backward passes (transposed+flipped weights in execution order, the
+// ReLU replaced by the saved mask, every layer's fp32 gradient stored for the weight-gradient kernels) and can store the
+// hidden activations (fp32, for a later backward).  The last layer ends in the shared fused epilogue (conv_common.h).
+// Used when every layer is 64 -> 64 (the ODEConvGRU dynamics) and a fused weight image is present; batches below 256 leave
+// CUs idle -- at B = 64 one f evaluation still takes ~1/3 of five bf16 launches.
+#include "conv_common.h"
+
+namespace odehip {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+constexpr int kFS = 144;                   // bytes per pixel of an activation tile (64 ch bf16 + 16 pad)
+constexpr int kFTile = 18 * 18 * kFS;      // 46,656 B
+constexpr int kFUnit = 8192;               // one tap of one layer
+constexpr int kFStages = 6;
+constexpr int kFusedLds = 2 * kFTile + kFStages * kFUnit;
+
+template <int N>
+__device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// DBG: diagnostic instantiation that honours the ablation flags in fa.last.debug (1 no weight DMA, 2 no MFMA and no operand
+// reads, 64 MFMA on constant operands); the production instantiation has no such branches in its inner loop.
+template <bool DBG>
+__global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const act0 = smem;
+  char* const act1 = smem + kFTile;
+  char* const ring = smem + 2 * kFTile;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  if (fa.last.skip && *fa.last.skip) return;
+  const int NL = fa.n_layers, U = NL * 9;
+  const int dbg = DBG ? fa.last.debug : 0;
+
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(fa.w_fused, (unsigned)(U * kFUnit));
+  const int vw = lane * 16;
+  auto issue = [&](int u, int stage) {  // one 1-KiB piece per wave
+    if (DBG && (dbg & 1)) return;
+    dma16(rw, ring + stage * kFUnit + wave * 1024, vw, u * kFUnit + wave * 1024);
+  };
+#pragma unroll
+  for (int u = 0; u < kFStages - 1; ++u)
+    if (u < U) issue(u, u);
+
+  // zero borders of both tiles (68 pixels x 144 B each), then the input: fp32 quads -> bf16
+  for (int i = threadIdx.x; i < 2 * 68 * 9; i += 512) {
+    const int t = i / (68 * 9), r = i % (68 * 9), p = r / 9, c16 = r % 9;
+    int row, col;
+    if (p < 18) { row = 0; col = p; }
+    else if (p < 36) { row = 17; col = p - 18; }
+    else if (p < 52) { row = p - 36 + 1; col = 0; }
+    else { row = p - 52 + 1; col = 17; }
+    *(f32x4*)((t ? act1 : act0) + (row * 18 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+    const f32x4* src = (const f32x4*)(fa.x + (size_t)b * 64 * kPix);
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[i * 512 + threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = i * 512 + (int)threadIdx.x, p = idx & 255, q = idx >> 8;
+      *(u32x2*)(act0 + (((p >> 4) + 1) * 18 + (p & 15) + 1) * kFS + q * 8) = u32x2{pk_bf16(v[i].x, v[i].y), pk_bf16(v[i].z, v[i].w)};
+    }
+  }
+
+  const int i32 = lane & 31, kq = lane >> 5;
+  const int px = i32 & 15, pyl = i32 >> 4;
+  const int P = (wave * 2 + pyl) * 16 + px;                       // pixel of this lane
+  const int boff = ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + kq * 16;
+  bool drain = true;  // the next wait is a full one (first unit; after an epilogue that issued global loads / stores)
+  f32x16 acc0, acc1;
+  for (int e = 0; e < NL; ++e) {
+    const char* in = ((e & 1) ? act1 : act0) + boff;
+    char* out = (e & 1) ? act0 : act1;
+    acc0 = bias_init(fa.bias[e], 0, kq);
+    acc1 = bias_init(fa.bias[e], 1, kq);
+    const int s0 = (e & 1) * 3;  // ring stage of tap 0 of this layer: (9 e) mod 6
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int u = e * 9 + tap;
+      const int stage = (s0 + tap) % kFStages;
+      // unit u landed?  each wave has one DMA per unit in flight, issued kFStages-1 units ahead; the tail just drains
+      if (drain || u + kFStages - 2 >= U) wait_le<0>(); else wait_le<kFStages - 2>();
+      drain = false;
+      // raw barrier (a __syncthreads() would drain vmcnt to 0 and serialise the ring): after lgkmcnt(0) this wave's LDS writes
+      // (input staging, epilogue) are complete; unit u is then in LDS for every wave and every wave is done with unit u-1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (u + kFStages - 1 < U) issue(u + kFStages - 1, (stage + kFStages - 1) % kFStages);
+      if (DBG && (dbg & 2)) continue;
+      const char* wb = ring + stage * kFUnit + vw;
+      const char* xb = in + ((tap / 3 - 1) * 18 + (tap % 3 - 1)) * kFS;
+      bf16x8 xv[4], w0[4], w1[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        xv[cb] = *(const bf16x8*)(xb + cb * 32);
+        w0[cb] = *(const bf16x8*)(wb + (cb * 2 + 0) * 1024);
+        w1[cb] = *(const bf16x8*)(wb + (cb * 2 + 1) * 1024);
+      }
+      if (DBG && (dbg & 64)) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) xv[cb] = w0[cb] = w1[cb] = w0[0];
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[cb], xv[cb], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[cb], xv[cb], acc1, 0, 0, 0);
+      }
+    }
+    if (e == NL - 1) break;
+    // ---- hidden layer: ReLU (or the saved mask), optional fp32 store, bf16 into the other tile
+    float* st = fa.store[e];
+    const float* mk = fa.mask[e];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const f32x16& acc = mb ? acc1 : acc0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        const int Q = mb * 8 + 2 * g + kq;
+        const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+        if (mk) {
+          const f32x4 m = *(const f32x4*)(mk + off);
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        } else {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (st) *(f32x4*)(st + off) = v;
+        *(u32x2*)(out + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+      }
+    }
+    if (st || mk) drain = true;  // global stores / loads were issued behind the ring DMAs: the next wait drains everything
+  }
+  // ---- last layer: the shared fused epilogue (stage combine, error partials, reverse-sweep targets, ...)
+  epilogue(fa.last, acc0, b, 0, P, kq, wave, b * 16 + wave);
+  epilogue(fa.last, acc1, b, 1, P, kq, wave, b * 16 + 8 + wave);
+}
+
+// fused image of executed layer `e`: [tap][cb][mb][h][co32][8]
+__global__ __launch_bounds__(256) void pack_fused_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int transpose_flip) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // 9 * 4 * 2 * 64 * 8 = 36864 elements
+  if (idx >= 36864) return;
+  int r = idx;
+  const int j = r & 7; r >>= 3;
+  const int co_l = r & 31; r >>= 5;
+  const int h = r & 1; r >>= 1;
+  const int mb = r & 1; r >>= 1;
+  const int cb = r & 3; r >>= 2;
+  const int tap = r;
+  const int co = mb * 32 + co_l, ci = cb * 16 + h * 8 + j;
+  const float v = transpose_flip ? w[((size_t)ci * 64 + co) * 9 + (8 - tap)] : w[((size_t)co * 64 + ci) * 9 + tap];
+  out[idx] = (__bf16)v;
+}
+
+int launch_fstack_bf16(const FusedArgs& fa_in, int batch, hipStream_t stream) {
+  FusedArgs fa = fa_in;
+  fa.last.debug = g_debug_flags;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)fstack_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)fstack_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (fa.last.debug) hipLaunchKernelGGL(fstack_bf16_kernel<true>, dim3(batch), dim3(512), kFusedLds, stream, fa);
+  else hipLaunchKernelGGL(fstack_bf16_kernel<false>, dim3(batch), dim3(512), kFusedLds, stream, fa);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+}  // namespace odehip
+
+using namespace odehip;
+
+extern "C" size_t odehip_fused_bf16_weight_bytes(int n_layers) { return (size_t)n_layers * 9 * 8192; }
+
+extern "C" int odehip_pack_convstack_fused_bf16(const float* w_oihw, void* w_fused, int exec_index, int transpose_flip, void* stream) {
+  ODEHIP_REQUIRE(w_oihw && w_fused && exec_index >= 0 && exec_index < ODEHIP_MAX_LAYERS, "pack_convstack_fused_bf16: bad argument");
+  hipLaunchKernelGGL(pack_fused_bf16_kernel, dim3(144), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (__bf16*)((char*)w_fused + (size_t)exec_index * 9 * 8192), transpose_flip);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}

@@ -99,6 +99,18 @@ int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_bf16(const ConvArgs& a, hipStream_t stream);
 int launch_bf16_5x5(const ConvArgs& a, hipStream_t stream);
+
+// whole-stack bf16 launch (fstack_bf16.hip)
+struct FusedArgs {
+  const float* x;                          // stage input (B,64) Q4 fp32
+  const void* w_fused;                     // [layer][tap][cb 4][mb 2][lane 64][8] bf16, execution order
+  const float* bias[ODEHIP_MAX_LAYERS];    // per executed layer (null: none)
+  float* store[ODEHIP_MAX_LAYERS];         // fp32 Q4 output of executed layer e < n-1 (null: not stored)
+  const float* mask[ODEHIP_MAX_LAYERS];    // e < n-1: null -> ReLU, else output *= (mask > 0)
+  int n_layers;
+  ConvArgs last;                           // epilogue of the last executed layer (qout = 16)
+};
+int launch_fstack_bf16(const FusedArgs& fa, int batch, hipStream_t stream);
 extern int g_debug_flags;
 extern unsigned long long* g_debug_buf;
 
@@ -114,6 +126,13 @@ int enqueue_f(const odehip_convstack* f, const float* x_q4, int batch, float* pi
               float* plain_dst, const int* skip, hipStream_t stream);
 int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, float* const* hidden, float* ping, float* pong,
                      const CombineArgs* cmb, float* plain_dst, const int* skip, hipStream_t stream);
+
+// Input-gradient chain of one evaluation of f: gp[n_convs-1] holds the gradient w.r.t. f's output; for l = n_convs-1 .. 1 the
+// gradient w.r.t. conv l's input is masked with hidden[l-1] (ReLU) and written to gp[l-1]; conv 0 ends in `last` (combine 3
+// with last.bwd, or combine 1 with last.cmb; its src/weights/shape fields are filled here).  One fused bf16 launch when
+// f_dgrad carries a fused image, else one launch per layer.
+int enqueue_dgrad_chain(const odehip_convstack* f, const odehip_convstack* f_dgrad, int batch, float* const* gp,
+                        const float* const* hidden, const ConvArgs& last, hipStream_t stream);
 
 // one (gradient, activation, weight) triple of the batched weight-gradient kernels (wgrad.hip)
 struct WgradPair {

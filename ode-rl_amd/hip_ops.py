@@ -187,6 +187,27 @@ def pack_conv_weight_bf16_ks(w, transpose_flip=False):
     return out
 
 
+USE_FUSED = os.environ.get("ODEHIP_NO_FUSED") is None   # bf16 mode, 64-channel 3x3 stacks: whole f in one launch (fstack_bf16.hip)
+
+
+def pack_fused_bf16(convs, reverse_transposed=False):
+    """Fused bf16 image of a stack of 64 -> 64 3x3 convs in execution order (the input-gradient chain runs the layers
+    backwards with transposed + flipped weights)."""
+    lib = _lib.load()
+    n = len(convs)
+    out = torch.empty(lib.odehip_fused_bf16_weight_bytes(n), dtype=torch.uint8, device=convs[0].weight.device)
+    for e in range(n):
+        c = convs[n - 1 - e] if reverse_transposed else convs[e]
+        w = c.weight.detach().contiguous()
+        require_device_tensor(w, "conv weight")
+        _lib.check(lib.odehip_pack_convstack_fused_bf16(_ptr(w), _ptr(out), e, int(bool(reverse_transposed)), _stream()))
+    return out
+
+
+def _fusable(convs, ks):
+    return USE_FUSED and ks == 3 and all(c.in_channels == 64 and c.out_channels == 64 for c in convs)
+
+
 def _bf16_cell_ok(cell_input, hidden, ks):
     return ks == 5 and cell_input % 16 == 0 and hidden % 32 == 0 and cell_input + hidden <= 128
 
@@ -253,7 +274,9 @@ class PackedConvStack:
         bf16 = [pack_conv_weight_bf16(c.weight) if mode == "bf16" and _bf16_ok(c.in_channels, c.out_channels, ks) else None
                 for c in convs]
         bias = [c.bias.detach().contiguous() for c in convs]
+        fused = pack_fused_bf16(convs) if mode == "bf16" and _fusable(convs, ks) else None
         d = _lib.ConvStack()
+        d.w_fused = fused.data_ptr() if fused is not None else None
         d.n_convs = len(convs)
         d.ks = ks
         d.channels[0] = convs[0].in_channels
@@ -264,7 +287,7 @@ class PackedConvStack:
             d.w_bf16[i] = bf16[i].data_ptr() if bf16[i] is not None else None
             d.bias[i] = bias[i].data_ptr()
         d.final_tanh = int(self.final_tanh)
-        self._cache[mode] = dict(stamp=stamp, desc=d, keep=(packed, wino, bf16), bias=bias, dgrad=None)
+        self._cache[mode] = dict(stamp=stamp, desc=d, keep=(packed, wino, bf16, fused), bias=bias, dgrad=None)
         self.desc, self._bias = d, bias
         return d
 
@@ -279,7 +302,9 @@ class PackedConvStack:
                     if USE_WINOGRAD and d0.ks == 3 and c.out_channels % 16 == 0 else None for c in self.convs]
             bf16 = [pack_conv_weight_bf16(c.weight, transpose_flip=True)
                     if mode == "bf16" and _bf16_ok(c.out_channels, c.in_channels, d0.ks) else None for c in self.convs]
+            fused = pack_fused_bf16(self.convs, reverse_transposed=True) if mode == "bf16" and _fusable(self.convs, d0.ks) else None
             d = _lib.ConvStack()
+            d.w_fused = fused.data_ptr() if fused is not None else None
             d.n_convs, d.ks = d0.n_convs, d0.ks
             for i in range(len(self.convs) + 1):
                 d.channels[i] = d0.channels[i]
@@ -288,7 +313,7 @@ class PackedConvStack:
                 d.w_wino[i] = wino[i].data_ptr() if wino[i] is not None else None
                 d.w_bf16[i] = bf16[i].data_ptr() if bf16[i] is not None else None
                 d.bias[i] = ent["bias"][i].data_ptr()
-            ent["dgrad"] = (d, packed, wino, bf16)
+            ent["dgrad"] = (d, packed, wino, bf16, fused)
         return ent["dgrad"][0]
 
 

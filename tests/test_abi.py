@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     # odehip_conv_desc: 2 pointers, 5 ints (+pad), 4 pointers, 1 int (+pad)
     assert ctypes.sizeof(L.ConvDesc) == 8 * 2 + 4 * 5 + 4 + 8 * 5 + 8
     # odehip_convstack: 2 ints + 9 ints (+pad), 3 arrays of 8 pointers, 1 int (+pad)
-    assert ctypes.sizeof(L.ConvStack) == 4 * 2 + 4 * 9 + 4 + 4 * 8 * 8 + 8
+    assert ctypes.sizeof(L.ConvStack) == 4 * 2 + 4 * 9 + 4 + 4 * 8 * 8 + 8 + 8
     assert L.MAX_LAYERS == 8 and L.MAX_STAGES == 7
 
 
