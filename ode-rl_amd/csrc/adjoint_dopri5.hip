@@ -427,7 +427,7 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
     }
     ODEHIP_CHECK_HIP(hipMemcpyAsync(table, host.data(), (size_t)n_eval * sizeof(WgradPair), hipMemcpyHostToDevice, stream));
     ODEHIP_CHECK_HIP(hipStreamSynchronize(stream));
-    rc = launch_wgrad(table, n_eval, batch, 4, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream);
+    rc = launch_wgrad(table, n_eval, batch, 4, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream, f->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
   if (stats_host) {

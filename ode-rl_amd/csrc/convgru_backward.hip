@@ -504,7 +504,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
       host[idx].pad_[0] = host[idx].pad_[1] = host[idx].pad_[2] = 0.0f;
     }
     if ((rc = put_table(T)) != ODEHIP_OK) return rc;
-    rc = launch_wgrad(table, T, batch, 4, slabs, gr->f_w[l], gr->f_b[l], e->f_enc.channels[l + 1], e->f_enc.channels[l], stream);
+    rc = launch_wgrad(table, T, batch, 4, slabs, gr->f_w[l], gr->f_b[l], e->f_enc.channels[l + 1], e->f_enc.channels[l], stream, (&e->f_enc)->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
   // ConvGRU convs on cat(x, state): the two halves of the input are separate tensors

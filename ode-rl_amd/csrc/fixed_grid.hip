@@ -128,7 +128,7 @@ static int wgrad_all_layers(const odehip_convstack* f, const FixedLayout& L, voi
       }
       hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
     }
-    int rc = launch_wgrad(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream);
+    int rc = launch_wgrad(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream, f->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
   return ODEHIP_OK;

@@ -141,8 +141,9 @@ struct WgradPair {
   float scale;     // weight of this evaluation in the sum (1 for discretise-then-optimise; dt*b_s for the adjoint)
   float pad_[3];
 };
+// bf16 = true: operands rounded to bf16 (fp32 accumulation), for stacks running in bf16 compute mode
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
-                 int cin, hipStream_t stream);
+                 int cin, hipStream_t stream, bool bf16 = false);
 int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
                       int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
                       hipStream_t stream);

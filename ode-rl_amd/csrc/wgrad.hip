@@ -355,8 +355,12 @@ int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esp
                                    a_quad0, write_bias, stream);
 }
 
+int launch_wgrad_bf16(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                      int cin, hipStream_t stream);
+
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
-                 int cin, hipStream_t stream) {
+                 int cin, hipStream_t stream, bool bf16) {
+  if (bf16) return launch_wgrad_bf16(table_dev, n_eval, batch, esplit, slabs, dw, db, cout, cin, stream);
   static bool attr_set = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -366,6 +370,165 @@ int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, 
   for (int co0 = 0; co0 < cout; co0 += 64)
     for (int ci0 = 0; ci0 < cin; ci0 += 64) {
       hipLaunchKernelGGL(wgrad64_kernel, dim3(batch, esplit), dim3(256), kWgradLds, stream, table_dev, n_eval, esplit, slabs,
+                         co0 / 4, cout / 4, ci0 / 4, cin / 4);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, cin,
+                         co0, ci0);
+    }
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+
+// =====================================================================================================================
+// bf16 variant (BASELINE.json configs[4]: bf16 compute): dW = sum G^T A with G and A rounded to bf16, fp32 accumulation.
+// The contraction index of a weight gradient is the PIXEL, but the activations are pixel-major ([pixel][channel], what the
+// forward kernels want), so both MFMA operands are column reads of their LDS tiles: gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: a 4 x 16 block delivered column-major) makes them directly, no transposed copy exists.
+//   LDS: G tile [256 px][64 co] and A tile [18][18][64 ci] (zero border = the conv padding), bf16, 192 B per pixel (the
+//   128 data bytes + 64: the four pixel rows of a transposed read then fall on disjoint banks).
+//   One K-step = one image row (16 pixels); wave w owns the 32(co) x 32(ci) block (w & 1, w >> 1) of all 9 taps:
+//   2 + 18 transposed reads feed 9 v_mfma_f32_32x32x16_bf16.  The next evaluation's 128 KiB of fp32 activations are loaded
+//   into registers while the current one is multiplied (global latency hidden behind the MFMAs), then rounded into LDS.
+// Same slab output and fixed-order reduction as the fp32 kernel: deterministic.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+
+constexpr int kWS = 192;                       // bytes per pixel in the bf16 tiles
+constexpr int kWG = 256 * kWS;                 // G tile
+constexpr int kWA = 18 * 18 * kWS;             // A tile
+constexpr int kWgradBf16Lds = kWG + kWA;
+
+__device__ __forceinline__ unsigned pkw(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ bf16x8w tr_pair(const char* p) {  // two transposed reads: 8 consecutive pixel rows of this lane's column
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * kWS));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8w, v);
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad64_bf16_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                              float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                              int a_quads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const gt = smem;
+  char* const at = smem + kWG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, es = blockIdx.y;
+  const int mb = wave & 1, nb = wave >> 1;
+
+  // zero border of the A tile (68 pixels x 128 data bytes)
+  for (int i = tid; i < 68 * 8; i += 256) {
+    const int p = i >> 3, c16 = i & 7;
+    int row, col;
+    if (p < 18) { row = 0; col = p; }
+    else if (p < 36) { row = 17; col = p - 18; }
+    else if (p < 52) { row = p - 36 + 1; col = 0; }
+    else { row = p - 52 + 1; col = 17; }
+    *(f32x4*)(at + (row * 18 + col) * kWS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  f32x16w acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  f32x4 bsum[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane bases of the transposed reads: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 of the group's 16
+  const int grp = lane >> 4, l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, h = lane >> 5;
+  const char* gbase = gt + (8 * h + q) * kWS + (mb * 32 + 16 * (grp & 1) + 4 * p4) * 2;
+  const char* abase = at + (8 * h + q) * kWS + (nb * 32 + 16 * (grp & 1) + 4 * p4) * 2;  // + (row*18 + col offset) * kWS per tap
+
+  f32x4 gv[16], av[16];
+  float esc = 0.0f;
+  auto prefetch = [&](int e) {
+    const WgradPair pr = table[e];
+    esc = pr.scale;
+    const f32x4* g = (const f32x4*)(pr.g + ((size_t)b * g_quads + g_quad0) * 4 * kPix) + tid;
+    const f32x4* a = (const f32x4*)(pr.a + ((size_t)b * a_quads + a_quad0) * 4 * kPix) + tid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gv[i] = g[i * 256];
+      av[i] = a[i * 256];
+    }
+  };
+  if (es < n_eval) prefetch(es);
+  for (int e = es; e < n_eval; e += esplit) {
+    __syncthreads();  // every wave is done with the previous evaluation's tiles
+    {
+      const int prow = tid >> 4, pcol = tid & 15;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {   // quad i of pixel tid
+        const f32x4 g = gv[i] * esc;
+        bsum[i] += g;
+        *(u32x2w*)(gt + tid * kWS + i * 8) = u32x2w{pkw(g.x, g.y), pkw(g.z, g.w)};
+        *(u32x2w*)(at + ((prow + 1) * 18 + pcol + 1) * kWS + i * 8) = u32x2w{pkw(av[i].x, av[i].y), pkw(av[i].z, av[i].w)};
+      }
+    }
+    __syncthreads();
+    if (e + esplit < n_eval) prefetch(e + esplit);  // in flight while this evaluation is multiplied
+#pragma unroll 2
+    for (int y = 0; y < 16; ++y) {
+      const bf16x8w gf = tr_pair(gbase + y * 16 * kWS);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;  // tile coordinates: row y + dy, column x + dx (border included)
+        const bf16x8w af = tr_pair(abase + ((y + dy) * 18 + dx) * kWS);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, af, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  float* slab = slabs + (size_t)(b * esplit + es) * (64 * 64 * 9 + 64);
+  {
+    const int n = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = nb * 32 + n;
+        slab[((size_t)co * 64 + ci) * 9 + t] = acc[t][r];
+      }
+  }
+  // bias gradient: thread = pixel, bsum[i] = its four channels of quad i; fold the 256 pixels
+  __syncthreads();
+  float* red = (float*)smem;  // 4 waves x 64 channels
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[i][c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[wave * 64 + 4 * i + c] = v;
+    }
+  __syncthreads();
+  if (tid < 64) slab[64 * 64 * 9 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+}
+
+int launch_wgrad_bf16(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                      int cin, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int sf = 64 * 64 * 9 + 64;
+  for (int co0 = 0; co0 < cout; co0 += 64)
+    for (int ci0 = 0; ci0 < cin; ci0 += 64) {
+      hipLaunchKernelGGL(wgrad64_bf16_kernel, dim3(batch, esplit), dim3(256), kWgradBf16Lds, stream, table_dev, n_eval, esplit, slabs,
                          co0 / 4, cout / 4, ci0 / 4, cin / 4);
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, cin,
                          co0, ci0);

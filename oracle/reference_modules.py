@@ -14,8 +14,8 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------- dynamics f
 class _MixedConv(torch.autograd.Function):
     """nn.Conv2d with bf16 operands and fp32 accumulation, as the HIP bf16 path computes it (BASELINE.json configs[4]):
-    forward conv(bf16(x), bf16(W)) + b in fp32; backward: input gradient from bf16(g) and bf16(W); weight/bias gradients
-    in fp32 from the unrounded x and g."""
+    forward conv(bf16(x), bf16(W)) + b in fp32; backward: input gradient from bf16(g) and bf16(W); weight gradient from
+    bf16(x) and bf16(g) (fp32 accumulation); bias gradient from the unrounded g."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -27,7 +27,7 @@ class _MixedConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         pad = w.shape[-1] // 2
         gx = torch.nn.grad.conv2d_input(x.shape, w.bfloat16().float(), g.bfloat16().float(), padding=pad)
-        gw = torch.nn.grad.conv2d_weight(x, w.shape, g, padding=pad)
+        gw = torch.nn.grad.conv2d_weight(x.bfloat16().float(), w.shape, g.bfloat16().float(), padding=pad)
         return gx, gw, g.sum((0, 2, 3))
 
 
