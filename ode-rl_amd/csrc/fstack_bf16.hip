@@ -2,8 +2,9 @@
 // plus the Runge-Kutta stage combine of the last layer) in ONE launch, bf16 operands / fp32 accumulation (BASELINE.json
 // configs[4]).  One workgroup = one sample: with bf16 on the matrix cores a 64-channel layer of one 16x16 map is 2.2 us of MFMA
 // on one CU, so the five layers of f need no other workgroup -- and therefore no launch boundary and no trip through HBM between
-// layers: the hidden activations live in LDS as bf16 ([18][18][64] tiles with zero borders, ping-pong), the weights of all
-// layers stream through a 6-stage LDS ring, one tap (8 KiB: 64 co x 64 ci) per stage, counted s_waitcnt + one barrier per tap.
+// layers: the hidden activations live in LDS as bf16 (one [18][18][64] tile with a zero border, rewritten in place after a
+// barrier), the weights of all layers stream through a 3-stage LDS ring, one kernel row (3 taps, 24 KiB) per stage, counted
+// s_waitcnt + one raw barrier per row (four barriers per layer).
 //   wave w (8 waves, two per SIMD) owns image rows 2w, 2w+1 (32 pixels) and both 32-channel halves: 8 MFMAs
 //   (v_mfma_f32_32x32x16_bf16) per tap, the B operand shared by the two halves; 360 MFMAs per wave per 5-layer f.  (Four waves
 //   with twice the tile halve the weight-fragment reads but measured slower: with one wave per SIMD nothing hides the code
@@ -29,9 +30,9 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
 
 constexpr int kFS = 144;                   // bytes per pixel of an activation tile (64 ch bf16 + 16 pad)
 constexpr int kFTile = 18 * 18 * kFS;      // 46,656 B
-constexpr int kFUnit = 8192;               // one tap of one layer
-constexpr int kFStages = 6;
-constexpr int kFusedLds = 2 * kFTile + kFStages * kFUnit;
+constexpr int kFUnit = 3 * 8192;           // one kernel row (3 taps) of one layer
+constexpr int kFStages = 3;
+constexpr int kFusedLds = kFTile + kFStages * kFUnit;
 
 template <int N>
 __device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -41,35 +42,35 @@ __device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" :
 template <bool DBG>
 __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const act0 = smem;
-  char* const act1 = smem + kFTile;
-  char* const ring = smem + 2 * kFTile;
+  char* const act = smem;
+  char* const ring = smem + kFTile;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
   if (fa.last.skip && *fa.last.skip) return;
-  const int NL = fa.n_layers, U = NL * 9;
+  const int NL = fa.n_layers, U = NL * 3;
   const int dbg = DBG ? fa.last.debug : 0;
 
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(fa.w_fused, (unsigned)(U * kFUnit));
   const int vw = lane * 16;
-  auto issue = [&](int u, int stage) {  // one 1-KiB piece per wave
+  auto issue = [&](int u, int stage) {  // three 1-KiB pieces per wave
     if (DBG && (dbg & 1)) return;
-    dma16(rw, ring + stage * kFUnit + wave * 1024, vw, u * kFUnit + wave * 1024);
-  };
 #pragma unroll
-  for (int u = 0; u < kFStages - 1; ++u)
-    if (u < U) issue(u, u);
+    for (int j = 0; j < 3; ++j)
+      dma16(rw, ring + stage * kFUnit + (wave * 3 + j) * 1024, vw, u * kFUnit + (wave * 3 + j) * 1024);
+  };
+  issue(0, 0);
+  if (U > 1) issue(1, 1);
 
-  // zero borders of both tiles (68 pixels x 144 B each), then the input: fp32 quads -> bf16
-  for (int i = threadIdx.x; i < 2 * 68 * 9; i += 512) {
-    const int t = i / (68 * 9), r = i % (68 * 9), p = r / 9, c16 = r % 9;
+  // zero border of the tile (68 pixels x 144 B), then the input: fp32 quads -> bf16
+  for (int i = threadIdx.x; i < 68 * 9; i += 512) {
+    const int p = i / 9, c16 = i % 9;
     int row, col;
     if (p < 18) { row = 0; col = p; }
     else if (p < 36) { row = 17; col = p - 18; }
     else if (p < 52) { row = p - 36 + 1; col = 0; }
     else { row = p - 52 + 1; col = 17; }
-    *(f32x4*)((t ? act1 : act0) + (row * 18 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(act + (row * 18 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   {
     const f32x4* src = (const f32x4*)(fa.x + (size_t)b * 64 * kPix);
@@ -79,56 +80,57 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = i * 512 + (int)threadIdx.x, p = idx & 255, q = idx >> 8;
-      *(u32x2*)(act0 + (((p >> 4) + 1) * 18 + (p & 15) + 1) * kFS + q * 8) = u32x2{pk_bf16(v[i].x, v[i].y), pk_bf16(v[i].z, v[i].w)};
+      *(u32x2*)(act + (((p >> 4) + 1) * 18 + (p & 15) + 1) * kFS + q * 8) = u32x2{pk_bf16(v[i].x, v[i].y), pk_bf16(v[i].z, v[i].w)};
     }
   }
 
   const int i32 = lane & 31, kq = lane >> 5;
   const int px = i32 & 15, pyl = i32 >> 4;
   const int P = (wave * 2 + pyl) * 16 + px;                       // pixel of this lane
-  const int boff = ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + kq * 16;
+  const char* const in = act + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + kq * 16;
   bool drain = true;  // the next wait is a full one (first unit; after an epilogue that issued global loads / stores)
   f32x16 acc0, acc1;
   for (int e = 0; e < NL; ++e) {
-    const char* in = ((e & 1) ? act1 : act0) + boff;
-    char* out = (e & 1) ? act0 : act1;
     acc0 = bias_init(fa.bias[e], 0, kq);
     acc1 = bias_init(fa.bias[e], 1, kq);
-    const int s0 = (e & 1) * 3;  // ring stage of tap 0 of this layer: (9 e) mod 6
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int u = e * 9 + tap;
-      const int stage = (s0 + tap) % kFStages;
-      // unit u landed?  each wave has one DMA per unit in flight, issued kFStages-1 units ahead; the tail just drains
-      if (drain || u + kFStages - 2 >= U) wait_le<0>(); else wait_le<kFStages - 2>();
+    for (int r = 0; r < 3; ++r) {  // unit = kernel row r of layer e; the ring stage is u mod 3 = r because units per layer = stages
+      const int u = e * 3 + r;
+      // unit u landed?  each wave has three DMAs per unit in flight, one unit issued beyond u (the last unit drains)
+      if (drain || u + 1 >= U) wait_le<0>(); else wait_le<3>();
       drain = false;
       // raw barrier (a __syncthreads() would drain vmcnt to 0 and serialise the ring): after lgkmcnt(0) this wave's LDS writes
-      // (input staging, epilogue) are complete; unit u is then in LDS for every wave and every wave is done with unit u-1
+      // (input staging, previous layer's epilogue) are complete; unit u is in LDS for every wave, every wave is done with u-1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (u + kFStages - 1 < U) issue(u + kFStages - 1, (stage + kFStages - 1) % kFStages);
+      if (u + 2 < U) issue(u + 2, (r + 2) % 3);
       if (DBG && (dbg & 2)) continue;
-      const char* wb = ring + stage * kFUnit + vw;
-      const char* xb = in + ((tap / 3 - 1) * 18 + (tap % 3 - 1)) * kFS;
-      bf16x8 xv[4], w0[4], w1[4];
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        xv[cb] = *(const bf16x8*)(xb + cb * 32);
-        w0[cb] = *(const bf16x8*)(wb + (cb * 2 + 0) * 1024);
-        w1[cb] = *(const bf16x8*)(wb + (cb * 2 + 1) * 1024);
-      }
-      if (DBG && (dbg & 64)) {
+      for (int c = 0; c < 3; ++c) {  // tap (dy, dx) = (r - 1, c - 1)
+        const char* wb = ring + r * kFUnit + c * 8192 + vw;
+        const char* xb = in + ((r - 1) * 18 + (c - 1)) * kFS;
+        bf16x8 xv[4], w0[4], w1[4];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) xv[cb] = w0[cb] = w1[cb] = w0[0];
-      }
+        for (int cb = 0; cb < 4; ++cb) {
+          xv[cb] = *(const bf16x8*)(xb + cb * 32);
+          w0[cb] = *(const bf16x8*)(wb + (cb * 2 + 0) * 1024);
+          w1[cb] = *(const bf16x8*)(wb + (cb * 2 + 1) * 1024);
+        }
+        if (DBG && (dbg & 64)) {
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[cb], xv[cb], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[cb], xv[cb], acc1, 0, 0, 0);
+          for (int cb = 0; cb < 4; ++cb) xv[cb] = w0[cb] = w1[cb] = w0[0];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[cb], xv[cb], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[cb], xv[cb], acc1, 0, 0, 0);
+        }
       }
     }
     if (e == NL - 1) break;
-    // ---- hidden layer: ReLU (or the saved mask), optional fp32 store, bf16 into the other tile
+    // ---- hidden layer: ReLU (or the saved mask), optional fp32 store, bf16 back into the SAME tile once every wave has read it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     float* st = fa.store[e];
     const float* mk = fa.mask[e];
 #pragma unroll
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (st) *(f32x4*)(st + off) = v;
-        *(u32x2*)(out + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+        *(u32x2*)(act + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
       }
     }
     if (st || mk) drain = true;  // global stores / loads were issued behind the ring DMAs: the next wait drains everything
