@@ -42,6 +42,8 @@ def alloc_workspace(nbytes, device):
     full = torch.empty(nbytes + _CANARY, dtype=torch.uint8, device=device)
     full[nbytes:].fill_(0xA5)
     view = full[:nbytes]
+    if len(_guarded) >= 64:   # forget workspaces that have been freed (one is allocated per training-mode forward)
+        _guarded[:] = [(r, n) for r, n in _guarded if r() is not None]
     _guarded.append((weakref.ref(full), nbytes))
     view._odehip_full = full   # keeps the guard alive as long as the view
     return view
