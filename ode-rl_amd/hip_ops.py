@@ -72,6 +72,32 @@ def workspace(key, nbytes, device):
     return buf
 
 
+_t_cache = {}
+
+
+def host_times(t):
+    """float64 host copy of a 1-D time tensor.  A device-resident `t` costs a device->host copy (a stream synchronisation);
+    it is cached per (base tensor OBJECT, version, view geometry): the base is held by weak reference, so a new tensor that
+    happens to reuse the address of a freed one can never hit the cache."""
+    import weakref
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.float64)
+    if t.dim() != 1:
+        raise AssertionError("`t` must be one dimensional")
+    if not t.is_cuda:
+        return t.detach().to(torch.float64)
+    base = t._base if t._base is not None else t
+    key = (id(base), base._version, t.storage_offset(), t.numel(), t.stride(0) if t.numel() > 1 else 1, t.dtype)
+    hit = _t_cache.get(key)
+    if hit is not None and hit[0]() is base:
+        return hit[1]
+    if len(_t_cache) > 64:
+        _t_cache.clear()
+    host = t.detach().to("cpu", torch.float64)
+    _t_cache[key] = (weakref.ref(base), host)
+    return host
+
+
 def nchw_to_q4(x):
     require_device_tensor(x, "x")
     x = x.contiguous()
@@ -664,7 +690,7 @@ def odeconvgru_encode_train(enc, inputs, timesteps):
     t, b, c = inputs.shape[0], inputs.shape[1], inputs.shape[2]
     if inputs.dim() != 5 or tuple(inputs.shape[3:]) != (16, 16) or c != d.cell.hidden:
         raise ValueError(f"inputs must be (T,B,{d.cell.hidden},16,16) time-first (got {tuple(inputs.shape)})")
-    t64 = [float(v) for v in timesteps.detach().to("cpu", torch.float64).tolist()]
+    t64 = [float(v) for v in host_times(timesteps).tolist()]
     assert t == len(t64), "Sequence length should be same as time_steps"
     lib = _lib.load()
     nbytes = lib.odehip_encoder_train_workspace_bytes(ctypes.byref(d), t, b)
@@ -711,7 +737,7 @@ def odeconvgru_encode(enc, inputs, timesteps, want_latent=False):
     t, b, c = inputs.shape[0], inputs.shape[1], inputs.shape[2]
     if inputs.dim() != 5 or tuple(inputs.shape[3:]) != (16, 16) or c != d.cell.hidden:
         raise ValueError(f"inputs must be (T,B,{d.cell.hidden},16,16) time-first (got {tuple(inputs.shape)})")
-    t64 = [float(v) for v in timesteps.detach().to("cpu", torch.float64).tolist()]
+    t64 = [float(v) for v in host_times(timesteps).tolist()]
     assert t == len(t64), "Sequence length should be same as time_steps"
     lib = _lib.load()
     nbytes = lib.odehip_encoder_workspace_bytes(ctypes.byref(d), t, b)

@@ -15,25 +15,10 @@ from . import hip_ops
 
 FIXED_GRID = ("euler", "midpoint", "rk4")
 last_stats = {}  # nfe / n_accept / n_reject of the most recent dopri5 call (instrumentation)
-_t_cache = {}
 
 
 def _host_times(t):
-    """float64 host copy of t; cached per (storage, version) so a device-resident t syncs once."""
-    if not isinstance(t, torch.Tensor):
-        t = torch.as_tensor(t, dtype=torch.float64)
-    if t.dim() != 1:
-        raise AssertionError("`t` must be one dimensional")
-    if not t.is_cuda:
-        return t.detach().to(torch.float64)
-    key = (t.data_ptr(), t._version, t.numel(), t.dtype)
-    hit = _t_cache.get(key)
-    if hit is None:
-        if len(_t_cache) > 64:
-            _t_cache.clear()
-        hit = t.detach().to("cpu", torch.float64)
-        _t_cache[key] = hit
-    return hit
+    return hip_ops.host_times(t)
 
 
 def _check_monotone(t):

@@ -191,3 +191,22 @@ def test_decreasing_time_integrates_negated_dynamics(cuda, method):
         got = ode_rl_amd.odeint(f, z0.to(cuda), t, rtol=1e-4, atol=1e-5, method=method)
         ref = torchdiffeq_ref.odeint(_oracle_f(fa), z0, t, rtol=1e-4, atol=1e-5, method=method)
     assert rel_l2(got, ref) <= 1e-4
+
+
+def test_host_time_cache_never_serves_a_recycled_address(cuda):
+    """Device-resident time grids are copied to the host once per tensor (a stream synchronisation); a NEW tensor that lands
+    on the address of a freed one must not be served the old values."""
+    import ode_rl_amd
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
+    z0 = torch.randn(1, 64, 16, 16, device=cuda) * 0.5
+    outs = []
+    with torch.no_grad():
+        for scale in (1.0, 2.0, 3.0):
+            t = torch.tensor([0.0, 0.1, 0.3], dtype=torch.float64, device=cuda) * scale   # freed each iteration: same address next time
+            outs.append(ode_rl_amd.odeint(f, z0, t, method="rk4")[-1].clone())
+            del t
+        ts = torch.tensor([0.0, 0.1, 0.3, 0.0, 0.2, 0.6], dtype=torch.float64, device=cuda)
+        a = ode_rl_amd.odeint(f, z0, ts[:3], method="rk4")[-1]       # views of one long-lived tensor: cached per view geometry
+        b = ode_rl_amd.odeint(f, z0, ts[3:], method="rk4")[-1]
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    assert torch.equal(a, outs[0]) and torch.equal(b, outs[1])
