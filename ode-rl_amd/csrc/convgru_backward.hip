@@ -524,8 +524,12 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
       if ((rc = put_table(T)) != ODEHIP_OK) return rc;
       for (int co0 = 0; co0 < J.g_ch; co0 += 64)
         for (int ci0 = 0; ci0 < C; ci0 += 64) {
-          rc = launch_wgrad_tile(table, T, batch, 4, slabs, J.dw, J.db, ks, 2 * C, co0, half * C + ci0, J.g_ch / 4, co0 / 4, C / 4,
-                                 ci0 / 4, half == 0 && ci0 == 0, stream);
+          if (ks == 5 && e->cell.w_gates_bf16)  // bf16 compute mode: operands rounded to bf16, fp32 accumulation
+            rc = launch_wgrad_tile_bf16_5x5(table, T, batch, 4, slabs, J.dw, J.db, 2 * C, co0, half * C + ci0, J.g_ch / 4, co0 / 4, C / 4,
+                                            ci0 / 4, half == 0 && ci0 == 0, stream);
+          else
+            rc = launch_wgrad_tile(table, T, batch, 4, slabs, J.dw, J.db, ks, 2 * C, co0, half * C + ci0, J.g_ch / 4, co0 / 4, C / 4,
+                                   ci0 / 4, half == 0 && ci0 == 0, stream);
           if (rc != ODEHIP_OK) return rc;
         }
     }
@@ -662,8 +666,12 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
       const int a_ch = half == 0 ? I : H;
       for (int co0 = 0; co0 < jobs[j].g_ch; co0 += 64)
         for (int ci0 = 0; ci0 < a_ch; ci0 += 64) {
-          rc = launch_wgrad_tile(table, 1, batch, 4, slabs, jobs[j].dw, jobs[j].db, ks, I + H, co0, half * I + ci0, jobs[j].g_ch / 4,
-                                 co0 / 4, a_ch / 4, ci0 / 4, half == 0 && ci0 == 0, stream);
+          if (ks == 5 && c->w_gates_bf16)
+            rc = launch_wgrad_tile_bf16_5x5(table, 1, batch, 4, slabs, jobs[j].dw, jobs[j].db, I + H, co0, half * I + ci0,
+                                            jobs[j].g_ch / 4, co0 / 4, a_ch / 4, ci0 / 4, half == 0 && ci0 == 0, stream);
+          else
+            rc = launch_wgrad_tile(table, 1, batch, 4, slabs, jobs[j].dw, jobs[j].db, ks, I + H, co0, half * I + ci0, jobs[j].g_ch / 4,
+                                   co0 / 4, a_ch / 4, ci0 / 4, half == 0 && ci0 == 0, stream);
           if (rc != ODEHIP_OK) return rc;
         }
     }

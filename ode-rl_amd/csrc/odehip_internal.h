@@ -148,6 +148,10 @@ int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esp
                       int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
                       hipStream_t stream);
 
+int launch_wgrad_tile_bf16_5x5(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
+                               int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
+                               hipStream_t stream);
+
 // Dormand-Prince 5(4) tableau as torchdiffeq 0.2.1 holds it (_impl/dopri5.py): beta rows, c_sol (= last beta row, padded),
 // c_error = c_sol - 4th-order weights, c_mid (dense-output midpoint weights)
 namespace dp5 {

@@ -518,6 +518,139 @@ __global__ __launch_bounds__(256, 1) void wgrad64_bf16_kernel(const WgradPair* _
   if (tid < 64) slab[64 * 64 * 9 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
 }
 
+// ---- the same for the 5x5 convs of the ConvGRU cell: tap rows [TY0, TY0+NTY) per launch (10 + 10 + 5 taps) so the accumulators
+// fit; A tile [20][20][64] with a 2-pixel zero border.  Slab layout and reduction of wgrad_tile_kernel.
+template <int KS, int TY0, int NTY>
+__global__ __launch_bounds__(256, 1) void wgrad_tile_bf16_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                                 float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                                 int a_quads) {
+  constexpr int HALO = KS / 2, NT = NTY * KS, W = 16 + 2 * HALO;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const gt = smem;
+  char* const at = smem + kWG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, es = blockIdx.y;
+  const int mb = wave & 1, nb = wave >> 1;
+
+  for (int i = tid; i < W * W * 8; i += 256) {  // zero the tile's data bytes once; the interior is rewritten per evaluation
+    const int p = i >> 3, c16 = i & 7;
+    *(f32x4*)(at + p * kWS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  f32x16w acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  f32x4 bsum[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int grp = lane >> 4, l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, h = lane >> 5;
+  const char* gbase = gt + (8 * h + q) * kWS + (mb * 32 + 16 * (grp & 1) + 4 * p4) * 2;
+  const char* abase = at + (8 * h + q) * kWS + (nb * 32 + 16 * (grp & 1) + 4 * p4) * 2;
+
+  f32x4 gv[16], av[16];
+  float esc = 0.0f;
+  auto prefetch = [&](int e) {
+    const WgradPair pr = table[e];
+    esc = pr.scale;
+    const f32x4* g = (const f32x4*)(pr.g + ((size_t)b * g_quads + g_quad0) * 4 * kPix) + tid;
+    const f32x4* a = (const f32x4*)(pr.a + ((size_t)b * a_quads + a_quad0) * 4 * kPix) + tid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gv[i] = g[i * 256];
+      av[i] = a[i * 256];
+    }
+  };
+  if (es < n_eval) prefetch(es);
+  for (int e = es; e < n_eval; e += esplit) {
+    __syncthreads();
+    {
+      const int prow = tid >> 4, pcol = tid & 15;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 g = gv[i] * esc;
+        if (TY0 == 0) bsum[i] += g;
+        *(u32x2w*)(gt + tid * kWS + i * 8) = u32x2w{pkw(g.x, g.y), pkw(g.z, g.w)};
+        *(u32x2w*)(at + ((prow + HALO) * W + pcol + HALO) * kWS + i * 8) = u32x2w{pkw(av[i].x, av[i].y), pkw(av[i].z, av[i].w)};
+      }
+    }
+    __syncthreads();
+    if (e + esplit < n_eval) prefetch(e + esplit);
+    for (int y = 0; y < 16; ++y) {
+      const bf16x8w gf = tr_pair(gbase + y * 16 * kWS);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int dy = TY0 + t / KS, dx = t % KS;  // tile coordinates (border included)
+        const bf16x8w af = tr_pair(abase + ((y + dy) * W + dx) * kWS);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, af, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  float* slab = slabs + (size_t)(b * esplit + es) * (64 * 64 * NT + 64);
+  {
+    const int n = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = nb * 32 + n;
+        slab[((size_t)co * 64 + ci) * NT + t] = acc[t][r];
+      }
+  }
+  __syncthreads();
+  float* red = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[i][c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[wave * 64 + 4 * i + c] = v;
+    }
+  __syncthreads();
+  if (tid < 64) slab[64 * 64 * NT + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+}
+
+template <int KS, int TY0, int NTY>
+static int launch_tile_bf16_part(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
+                                 int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
+                                 hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad_tile_bf16_kernel<KS, TY0, NTY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
+    attr_set = true;
+  }
+  constexpr int NT = NTY * KS, W = 16 + 2 * (KS / 2);
+  hipLaunchKernelGGL((wgrad_tile_bf16_kernel<KS, TY0, NTY>), dim3(batch, esplit), dim3(256), kWG + W * W * kWS, stream, table_dev, n_eval,
+                     esplit, slabs, g_quad0, g_quads, a_quad0, a_quads);
+  const int sf = 64 * 64 * NT + 64;
+  hipLaunchKernelGGL(wgrad_tile_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, NT, TY0 * KS,
+                     KS * KS, dw, db, cin_total, co0, ci0, (int)(write_bias && TY0 == 0));
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+// bf16 variant of launch_wgrad_tile for 5x5 layers; slabs: batch*esplit*(64*64*10+64) floats
+int launch_wgrad_tile_bf16_5x5(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,
+                               int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
+                               hipStream_t stream) {
+  int rc = launch_tile_bf16_part<5, 0, 2>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads,
+                                          a_quad0, write_bias, stream);
+  if (rc != ODEHIP_OK) return rc;
+  rc = launch_tile_bf16_part<5, 2, 2>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads,
+                                      a_quad0, write_bias, stream);
+  if (rc != ODEHIP_OK) return rc;
+  return launch_tile_bf16_part<5, 4, 1>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads,
+                                        a_quad0, write_bias, stream);
+}
+
 int launch_wgrad_bf16(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                       int cin, hipStream_t stream) {
   static bool attr_set = false;
