@@ -51,6 +51,8 @@ def parse():
                    help="dopri5 on N > 1 ranks: one error norm over the global batch (an all-reduce per attempted step)")
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                    help="compute dtype of the 3x3 convs: f32 (headline, exact) or bf16 operands + fp32 accumulate/state (configs[4])")
+    p.add_argument("--graph", action="store_true", help="diagnostic: replay the forward trajectory from a captured HIP graph")
+    p.add_argument("--side-stream", action="store_true", help="diagnostic: run the timed region on a non-default stream")
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,6 +170,24 @@ def main():
             allreduce_gradients(f.parameters())
         return o.detach()
 
+    if a.side_stream:   # diagnostic: run on a non-default stream
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(side)
+    if a.graph and not a.train:   # diagnostic: capture one forward trajectory in a HIP graph and replay it
+        gs = torch.cuda.Stream()
+        gs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(gs):
+            step()
+        torch.cuda.current_stream().wait_stream(gs)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = step()
+        eager_step = step
+
+        def step():
+            graph.replay()
+            return graph_out
     for _ in range(a.warmup):
         out = step()
     sync()
