@@ -293,6 +293,17 @@ int odehip_odeint_dopri5_backward(const odehip_convstack* f, const odehip_convst
                                   const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w, float* const* grad_b,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- EXPERIMENTAL, not used by the entry points above: Winograd F(4x4,3x3) for the 64 -> 64 3x3 layers with the input
+ * transform outside the matrix kernel (conv_f43.hip).  odehip_f43_transform_input turns a Q4 activation
+ * (B,64,16,16) into the transformed form V (odehip_f43_input_floats(B) floats), odehip_pack_conv_weight_f43 a weight into U
+ * (odehip_f43_weight_floats() floats), odehip_conv_f43 computes conv(+bias, +ReLU) from V and U into a Q4 tensor, n times
+ * back to back (n = 1 for the layer itself; n > 1 for timing). */
+size_t odehip_f43_weight_floats(void);
+size_t odehip_f43_input_floats(int batch);
+int odehip_pack_conv_weight_f43(const float* w_oihw, float* u, int transpose_flip, void* stream);
+int odehip_f43_transform_input(const float* src_q4, float* v, int batch, void* stream);
+int odehip_conv_f43(const float* v, const float* u, const float* bias, float* dst_q4, int batch, int relu, int n, void* stream);
+
 /* ---- optimizer step of the training loop (train_test.py:24,205: optim.Adam(model.parameters(), lr)) ------------------------ */
 
 /* One launch for every parameter tensor: torch.optim.Adam arithmetic (amsgrad off; weight_decay is the L2 form), `step` counts

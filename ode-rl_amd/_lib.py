@@ -106,6 +106,12 @@ SIGNATURES = {
                                                        ctypes.c_int, ctypes.c_void_p]),
     "odehip_debug_repeat_f": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p]),
+    "odehip_f43_weight_floats": (ctypes.c_size_t, []),
+    "odehip_f43_input_floats": (ctypes.c_size_t, [ctypes.c_int]),
+    "odehip_pack_conv_weight_f43": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_f43_transform_input": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "odehip_conv_f43": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
     "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),

@@ -244,6 +244,35 @@ def _bf16_ok(cin, cout, ks):
     return ks == 3 and cin % 16 == 0 and cin <= 128 and cin // 16 in (1, 2, 4, 8) and cout % 32 == 0
 
 
+# ---- experimental F(4x4,3x3) path (csrc/conv_f43.hip): building blocks only, not used by the solver entry points yet
+def f43_pack_weight(w, transpose_flip=False):
+    require_device_tensor(w, "weight")
+    w = w.detach().contiguous()
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise ValueError("the F(4x4,3x3) prototype serves 64 -> 64 3x3 layers only")
+    lib = _lib.load()
+    u = torch.empty(lib.odehip_f43_weight_floats(), dtype=torch.float32, device=w.device)
+    _lib.check(lib.odehip_pack_conv_weight_f43(_ptr(w), _ptr(u), int(bool(transpose_flip)), _stream()))
+    return u
+
+
+def f43_transform_input(x_q4):
+    require_device_tensor(x_q4, "x")
+    b = x_q4.shape[0]
+    if tuple(x_q4.shape) != (b, 16, 256, 4):
+        raise ValueError("f43_transform_input needs a Q4 tensor of 64 channels")
+    lib = _lib.load()
+    v = torch.empty(lib.odehip_f43_input_floats(b), dtype=torch.float32, device=x_q4.device)
+    _lib.check(lib.odehip_f43_transform_input(_ptr(x_q4.contiguous()), _ptr(v), b, _stream()))
+    return v
+
+
+def f43_conv(v, u, bias, batch, relu=False, repeat=1):
+    out = torch.empty((batch, 16, 256, 4), dtype=torch.float32, device=v.device)
+    _lib.check(_lib.load().odehip_conv_f43(_ptr(v), _ptr(u), _ptr(bias), _ptr(out), batch, int(bool(relu)), int(repeat), _stream()))
+    return out
+
+
 USE_WINOGRAD = os.environ.get("ODEHIP_NO_WINOGRAD") is None   # 3x3 layers with cin % 16 == 0 run the Winograd kernel (2.25x fewer MFMAs, still exact-fp32 arithmetic)
 
 
