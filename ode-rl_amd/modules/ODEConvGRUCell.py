@@ -3,9 +3,14 @@
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import hip_ops
 from ..odeint import conv_stack_of
 from .ConvGRUCell import ConvGRUCell
+
+
+DEBUG_NAN = os.environ.get("ODEHIP_DEBUG_NAN") is not None   # debug mode: reproduce the reference's NaN assertions
 
 
 class ODEConvGRUCell(nn.Module):
@@ -35,6 +40,8 @@ class ODEConvGRUCell(nn.Module):
             from ..autograd import encode_with_grad
             return encode_with_grad(enc, inputs, timesteps)
         mean, std, _ = hip_ops.odeconvgru_encode(enc, inputs, timesteps)
+        if DEBUG_NAN:   # the reference asserts on NaN inside its loop (:56,59); here once per call, and only on request (it syncs)
+            assert not torch.isnan(mean).any() and not torch.isnan(std).any(), "NaN in the encoder output"
         return mean, std
 
     def run_ode_conv_gru(self, inputs, timesteps, run_backwards=True, mask=None):
