@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--adjoint", action="store_true", help="--train through odeint_adjoint (dopri5: seminorm) instead of backward through the solver")
     p.add_argument("--global-step-control", action="store_true",
                    help="dopri5 on N > 1 ranks: one error norm over the global batch (an all-reduce per attempted step)")
+    p.add_argument("--shape", default="A", choices=["A", "V"], help="dynamics: A = ODEConvGRU (headline), V = VidODE latent shape")
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                    help="compute dtype of the 3x3 convs: f32 (headline, exact) or bf16 operands + fp32 accumulate/state (configs[4])")
     p.add_argument("--graph", action="store_true", help="diagnostic: replay the forward trajectory from a captured HIP graph")
@@ -125,7 +126,9 @@ def main():
     if a.dtype == "bf16":
         ode_rl_amd.set_compute_dtype("bf16")
     torch.manual_seed(0)
-    f = ode_rl_amd.ODEFunc(n_inputs=64, n_outputs=64, n_layers=3, n_units=64, downsize=False, nonlinear="relu",
+    # A = ODEConvGRU dynamics (5 x conv 64 -> 64); V = VidODE dynamics (128 -> 64 -> 64 -> 128; BASELINE configs[3])
+    C0, chans = (64, [64] * 6) if a.shape == "A" else (128, [128, 64, 64, 128])
+    f = ode_rl_amd.ODEFunc(n_inputs=C0, n_outputs=C0, n_layers=3 if a.shape == "A" else 2, n_units=64, downsize=False, nonlinear="relu",
                            final_act=False)
     state = {k: v.detach().clone() for k, v in f.state_dict().items()}
     f = f.to(dev)
@@ -135,7 +138,7 @@ def main():
     if a.atol is not None:
         solver.odeint_atol = a.atol
     g = torch.Generator().manual_seed(1234 + rank)
-    z0_cpu = torch.randn(a.batch, 64, 16, 16, generator=g) * 0.5
+    z0_cpu = torch.randn(a.batch, C0, 16, 16, generator=g) * 0.5
     z0 = z0_cpu.to(dev)
     T = a.frames
     t_cpu = torch.arange(T, 2 * T, dtype=torch.float64) / (2 * T)
@@ -151,7 +154,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    gout = torch.randn(T, a.batch, 64, 16, 16, generator=torch.Generator().manual_seed(99)).to(dev) if a.train else None
+    gout = torch.randn(T, a.batch, C0, 16, 16, generator=torch.Generator().manual_seed(99)).to(dev) if a.train else None
 
     def step():
         if not a.train:
@@ -199,7 +202,7 @@ def main():
     ev1.record()
     sync()
     wall = time.perf_counter() - t0
-    assert out.shape == (T, a.batch, 64, 16, 16) and bool(torch.isfinite(out).all())
+    assert out.shape == (T, a.batch, C0, 16, 16) and bool(torch.isfinite(out).all())
     dev_ms = ev0.elapsed_time(ev1)
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -213,7 +216,7 @@ def main():
             adj = dict(ode_rl_amd.last_adjoint_stats) if (a.train and a.adjoint) else None
         else:
             nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
-        n_convs = 5
+        n_convs = len(chans) - 1
         launches = nfe_per_step * n_convs * a.steps * (2 if a.train else 1)   # train: + the dgrad conv of every layer
         if a.method == "dopri5" and a.train and a.adjoint:  # adaptive adjoint: each augmented evaluation = forward + dgrad convs
             launches = (nfe_per_step + 2 * adj.get("nfe", 0)) * n_convs * a.steps
@@ -222,7 +225,7 @@ def main():
             launches = (nfe_per_step + 2 * (6 * acc + 1)) * n_convs * a.steps
         # ALGORITHMIC work of one 64->64 3x3 layer over the batch (direct-convolution FLOPs); the
         # Winograd kernel executes 2.25x fewer MFMA FLOPs for it, so `frac` is algorithmic throughput over the MFMA peak
-        flop_per_launch = conv_flops([64, 64], a.batch)
+        flop_per_launch = conv_flops(chans, a.batch) / n_convs      # average layer of f (A: every layer is 64 -> 64)
         per_launch_s = dev_ms * 1e-3 / launches                      # HIP events, incl. inter-kernel gaps
         achieved = flop_per_launch / per_launch_s / 1e12
         res = {
@@ -233,9 +236,9 @@ def main():
             "ms_per_step": wall / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"ODEConvGRU latents z0 (B={a.batch},64,16,16) per GPU, T={T} output frames "
+            "config": {"workload": f"{'ODEConvGRU' if a.shape == 'A' else 'VidODE'} latents z0 (B={a.batch},{C0},16,16) per GPU, T={T} output frames "
                                    f"({T - 1} intervals), " + (f"adaptive dopri5 rtol {solver.odeint_rtol:g} atol {solver.odeint_atol:g}" if a.method == "dopri5"
-                                                                else f"fixed-step {a.method} (3/8 rule)") + ", f = 5x conv3x3(64->64)+ReLU, "
+                                                                else f"fixed-step {a.method} (3/8 rule)") + ", f = " + ("5x conv3x3(64->64)+ReLU" if a.shape == "A" else "conv3x3 128->64->64->128 +ReLU (VidODE)") + ", "
                                    + (("forward + adjoint backward" + (" (seminorm)" if a.method == "dopri5" else "") if a.adjoint else
                                        "forward + backward (discretise-then-optimise)") if a.train else "forward only (BASELINE configs[1])"),
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}" + (", exact-global dopri5 step control" if (a.method == "dopri5" and a.global_step_control and world > 1)
@@ -245,7 +248,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>" if a.dtype == "f32" else "conv3x3_bf16_kernel<4>",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
-                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32") else None,
+                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A") else None,
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
                          "launches_timed": launches},
         }
