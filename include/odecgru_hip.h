@@ -157,12 +157,15 @@ int odehip_odeint_adjoint_backward(const odehip_convstack* f, const odehip_convs
  * parameter adjoint does not steer the step size (seminorm) and is accumulated by one weight-gradient launch per layer
  * at the end.  Synchronises `stream` once per attempted step (host-side step control).  `max_accept` bounds the number
  * of accepted steps over the whole backward pass (each keeps its activations); exceeding it returns ODEHIP_EINVAL.
- * stats_host (may be null): {f evaluations of the augmented system, accepted steps, rejected steps}. */
+ * stats_host (may be null): {f evaluations of the augmented system, accepted steps, rejected steps}.
+ * mixed_norm = 1 is torchdiffeq's DEFAULT adjoint norm: every parameter tensor's RMS error ratio also steers the steps; the
+ * parameter block is then integrated step by step (two batched weight-gradient launches per layer and attempt: its error
+ * estimate and its increment are both linear in the seven stages). */
 size_t odehip_adjoint_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int max_accept);
 int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host,
                                           int n_times, int batch, float rtol, float atol, const float* y_traj_nchw,
                                           const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
-                                          float* const* grad_b, int max_accept, int* stats_host, void* workspace,
+                                          float* const* grad_b, int max_accept, int mixed_norm, int* stats_host, void* workspace,
                                           size_t workspace_bytes, void* stream);
 
 /* ---- ConvGRU cell and the ODE-ConvGRU encoder (modules/ConvGRUCell.py:55-86, modules/ODEConvGRUCell.py:32-78) ---- */

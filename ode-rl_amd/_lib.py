@@ -152,7 +152,7 @@ SIGNATURES = {
                                                              ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
                                                              ctypes.c_void_p, ctypes.c_void_p,
                                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                                                             ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                                                             ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
                                                              ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_convgru_cell_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvGRUCellDesc), ctypes.c_int]),
     "odehip_convgru_cell_forward": (ctypes.c_int, [ctypes.POINTER(ConvGRUCellDesc), ctypes.c_void_p, ctypes.c_void_p,

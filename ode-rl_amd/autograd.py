@@ -180,7 +180,8 @@ class _AdjointDopri5(torch.autograd.Function):
         cfg = ctx.cfg
         stats = {}
         gz0, gws, gbs = hip_ops.odeint_adjoint_dopri5_backward(ctx.stack, ctx.t_host, y_traj, grad_out, cfg["adjoint_rtol"],
-                                                               cfg["adjoint_atol"], max_accept=cfg["max_accept"], stats=stats)
+                                                               cfg["adjoint_atol"], max_accept=cfg["max_accept"], stats=stats,
+                                                               mixed_norm=cfg["mixed_norm"])
         last_adjoint_stats.clear()
         last_adjoint_stats.update(stats)
         grads = []
@@ -196,10 +197,10 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
                    adjoint_method=None, adjoint_options=None, adjoint_params=None):
     """`torchdiffeq.odeint_adjoint(func, y0, t, rtol=, atol=, method=, adjoint_options=)`.
 
-    Fixed-grid methods: one backward step of the same method per interval.  dopri5: adaptive backward solve; only the
-    `adjoint_options={"norm": "seminorm"}` step control is implemented (the parameter adjoint does not steer the step
-    size -- torchdiffeq's recommended setting), so it has to be asked for explicitly; `max_accept` in adjoint_options
-    bounds the accepted backward steps whose activations are kept for the parameter gradients."""
+    Fixed-grid methods: one backward step of the same method per interval.  dopri5: adaptive backward solve with
+    torchdiffeq's default mixed norm (every parameter tensor's error ratio steers the steps too) or, with
+    `adjoint_options={"norm": "seminorm"}`, with the cheaper seminorm; `max_accept` in adjoint_options bounds the accepted
+    backward steps whose activations are kept."""
     from .odeint import FIXED_GRID, _check_monotone, _host_times, conv_stack_of, odeint
     if method is None:
         method = "dopri5"
@@ -221,9 +222,9 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     if method in FIXED_GRID:
         return _AdjointOdeint.apply(y0, th, method, stack, *params)
     adjoint_options = dict(adjoint_options or {})
-    if adjoint_options.get("norm") != "seminorm":
-        raise NotImplementedError('odeint_adjoint(HIP, dopri5): pass adjoint_options={"norm": "seminorm"}; the default mixed '
-                                  "norm (parameter adjoint steering the step size) is not implemented")
+    norm = adjoint_options.get("norm")
+    if norm not in (None, "mixed", "seminorm"):
+        raise ValueError(f'odeint_adjoint(HIP): adjoint_options["norm"] must be "seminorm" or omitted (torchdiffeq\'s mixed norm); got {norm!r}')
     unknown = set(adjoint_options) - {"norm", "max_accept"}
     if unknown:
         raise ValueError(f"odeint_adjoint(HIP): unsupported adjoint_options {sorted(unknown)}")
@@ -234,7 +235,8 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     cfg = dict(rtol=float(rtol), atol=float(atol), first_step=float(options.get("first_step") or 0.0),
                max_num_steps=int(options.get("max_num_steps") or 0),
                adjoint_rtol=float(rtol if adjoint_rtol is None else adjoint_rtol),
-               adjoint_atol=float(atol if adjoint_atol is None else adjoint_atol), max_accept=adjoint_options.get("max_accept"))
+               adjoint_atol=float(atol if adjoint_atol is None else adjoint_atol), max_accept=adjoint_options.get("max_accept"),
+               mixed_norm=norm != "seminorm")
     return _AdjointDopri5.apply(y0, th, cfg, stack, *params)
 
 

@@ -5,6 +5,7 @@
 // For i = T-1 .. 1 the augmented state (y, a_y, a_theta) is integrated from t[i] back to t[i-1] by a fresh dopri5 solve
 // on the flipped time axis (negated dynamics): initial-step heuristic, attempted steps with the error ratio
 //   max( rms(err_y / tol_y), rms(err_a / tol_a) )          (seminorm: the parameter block does not steer the steps)
+// (or, with torchdiffeq's default MIXED norm, the max over y, a_y and every parameter tensor's own RMS);
 // accept/reject and step-size update exactly as _adaptive_step/_optimal_step_size; the value at t[i-1] is the quartic
 // dense output of the last accepted step.  y is then reset to the stored y[i-1] and a_y += grad_out[i-1].
 //
@@ -96,10 +97,42 @@ __global__ __launch_bounds__(256) void adj_lincomb_kernel(AdjLin a, long long n4
 }
 
 
+// parameter block (mixed norm): tensor j = floats [off[j], off[j+1]) of the flattened parameter vector; one workgroup per tensor:
+// out[j] = sum ((a - b) / (atol + rtol * max(|r0|, |r0 + d|)))^2      (b, d may be null)
+struct ThetaSpans {
+  int off[2 * ODEHIP_MAX_LAYERS + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void theta_sumsq_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ r0, const float* __restrict__ d, float atol,
+                                                          float rtol, ThetaSpans sp, float* __restrict__ out) {
+  __shared__ float sh[256];
+  const int j = blockIdx.x;
+  float s = 0.0f;
+  for (int i = sp.off[j] + threadIdx.x; i < sp.off[j + 1]; i += 256) {
+    const float r = r0[i];
+    const float tol = atol + rtol * fmaxf(fabsf(r), d ? fabsf(r + d[i]) : fabsf(r));
+    const float v = (a[i] - (b ? b[i] : 0.0f)) / tol;
+    s += v * v;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[j] = sh[0];
+}
+// a += d
+__global__ __launch_bounds__(256) void theta_add_kernel(float* __restrict__ a, const float* __restrict__ d, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) a[i] += d[i];
+}
+
 struct AdjLayout {
   int T, B, C, NH, max_slots, n_part;
   size_t st, hid, slot_bytes;
-  size_t off_h, off_part, off_sums, off_ping, off_pong, off_y, off_go, off_a2, off_ky, off_ka, off_slots, off_tab, off_slab, total;
+  size_t off_h, off_part, off_sums, off_ping, off_pong, off_y, off_go, off_a2, off_ky, off_ka, off_slots, off_tab, off_slab, off_theta, total;
+  int P;  // floats of the flattened parameter vector (w0, b0, w1, b1, ...)
   AdjLayout(const odehip_convstack* f, int batch, int n_times, int max_accept) {
     T = n_times; B = batch; C = f->channels[0]; NH = f->n_convs - 1; max_slots = max_accept + 1;
     st = al256((size_t)B * C * kPix * 4);
@@ -123,6 +156,9 @@ struct AdjLayout {
     off_slots = take((size_t)max_slots * slot_bytes);
     off_tab = take((size_t)max_slots * 7 * sizeof(WgradPair));
     off_slab = take((size_t)B * 4 * (64 * 64 * 9 + 64) * 4);
+    P = 0;
+    for (int l = 0; l < f->n_convs; ++l) P += f->channels[l + 1] * f->channels[l] * 9 + f->channels[l + 1];
+    off_theta = take((size_t)5 * P * 4);  // mixed norm: running a_theta, error estimate, increment, K^theta at the two initial-step points
     total = o;
   }
   float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }
@@ -150,8 +186,8 @@ extern "C" size_t odehip_adjoint_dopri5_workspace_bytes(const odehip_convstack* 
 extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad,
                                                      const double* t_host, int n_times, int batch, float rtol, float atol,
                                                      const float* y_traj_nchw, const float* grad_out_nchw, float* grad_z0_nchw,
-                                                     float* const* grad_w, float* const* grad_b, int max_accept, int* stats_host,
-                                                     void* workspace, size_t workspace_bytes, void* stream_) {
+                                                     float* const* grad_w, float* const* grad_b, int max_accept, int mixed_norm,
+                                                     int* stats_host, void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(f_dgrad && t_host && y_traj_nchw && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace,
@@ -229,7 +265,7 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
       ps.n[j] = lens[j];
     }
     hipLaunchKernelGGL(adj_reduce_kernel, dim3(1), dim3(256), 0, stream, ps, sums);
-    ODEHIP_CHECK_HIP(hipMemcpyAsync(g_adj_host, sums, (size_t)count * 4, hipMemcpyDeviceToHost, stream));
+    ODEHIP_CHECK_HIP(hipMemcpyAsync(g_adj_host, sums, (size_t)(mixed_norm ? 8 + 4 * NL : count) * 4, hipMemcpyDeviceToHost, stream));
     ODEHIP_CHECK_HIP(hipStreamSynchronize(stream));
     for (int j = 0; j < count; ++j) out[j] = g_adj_host[j];
     return ODEHIP_OK;
@@ -248,6 +284,64 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
     hipLaunchKernelGGL(adj_lincomb_kernel, dim3(1024), dim3(256), 0, stream, a, n4);
   };
   auto rms = [&](float s) { return sqrtf((float)((double)s / N)); };
+
+  // ---- parameter block of the augmented state (mixed norm only)
+  const int P = L.P, NT = 2 * NL;
+  float* th_run = L.p(ws, L.off_theta);            // a_theta accumulated so far
+  float* th_err = th_run + P;                      // error estimate of the attempt
+  float* th_inc = th_err + P;                      // its increment h * sum b_s K_s (or the dense-output weights)
+  float* th_k1 = th_inc + P;                       // K^theta at the interval start / at the Euler point of the initial-step search
+  float* th_kf = th_k1 + P;
+  ThetaSpans spans;
+  memset(&spans, 0, sizeof(spans));
+  spans.count = NT;
+  {
+    int o = 0;
+    for (int l = 0; l < NL; ++l) {
+      spans.off[2 * l] = o;
+      o += f->channels[l + 1] * f->channels[l] * 9;
+      spans.off[2 * l + 1] = o;
+      o += f->channels[l + 1];
+    }
+    spans.off[NT] = o;
+  }
+  if (mixed_norm) ODEHIP_CHECK_HIP(hipMemsetAsync(th_run, 0, (size_t)P * 4, stream));
+  struct StageRef {
+    int slot, stage;
+    const float* x0;
+    float scale;
+  };
+  // out (flattened parameter layout) = sum_i scale_i * wgrad(evaluation i): one batched launch per layer
+  auto theta_wgrad = [&](const StageRef* ev, int n_ev, float* out) -> int {
+    WgradPair* tab = (WgradPair*)L.p(ws, L.off_tab);
+    float* slab = L.p(ws, L.off_slab);
+    for (int l = 0; l < NL; ++l) {
+      WgradPair host[8];
+      memset(host, 0, sizeof(host));
+      for (int i = 0; i < n_ev; ++i) {
+        host[i].g = L.gp(ws, ev[i].slot, ev[i].stage, l);
+        host[i].a = l == 0 ? ev[i].x0 : L.hidden(ws, ev[i].slot, ev[i].stage, l - 1);
+        host[i].scale = ev[i].scale;
+      }
+      float bits[8 * sizeof(WgradPair) / 4];
+      memcpy(bits, host, sizeof(host));
+      int r = upload_floats((float*)tab, bits, n_ev * (int)(sizeof(WgradPair) / 4), stream);
+      if (r != ODEHIP_OK) return r;
+      r = launch_wgrad(tab, n_ev, batch, 4, slab, out + spans.off[2 * l], out + spans.off[2 * l + 1], f->channels[l + 1],
+                       f->channels[l], stream, f->w_bf16[l] != nullptr);
+      if (r != ODEHIP_OK) return r;
+    }
+    return ODEHIP_OK;
+  };
+  // per-tensor sums of ((a - b) / tol)^2 into sums[8 .. 8+NT)
+  auto theta_sums = [&](const float* a, const float* b, const float* r0, const float* d, int which) {  // -> sums[8 + which*NT ..)
+    hipLaunchKernelGGL(theta_sumsq_kernel, dim3(NT), dim3(256), 0, stream, a, b, r0, d, atol, rtol, spans, sums + 8 + which * NT);
+  };
+  auto theta_rms_max = [&](const volatile float* host_sums) {
+    float m = 0.0f;
+    for (int j = 0; j < NT; ++j) m = fmaxf(m, sqrtf((float)((double)host_sums[j] / (double)(spans.off[j + 1] - spans.off[j]))));
+    return m;
+  };
 
   struct Entry {
     int slot, stage;
@@ -280,11 +374,21 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
     sumsq(1, a_cur, nullptr, a_cur);
     sumsq(2, ky[0], nullptr, y_cur);
     sumsq(3, ka[0], nullptr, a_cur);
+    if (mixed_norm) {  // parameter block: state a_theta, derivative K^theta_1 = wgrad at the interval start
+      const StageRef e0 = {slot, 0, y_cur, 1.0f};
+      if ((rc = theta_wgrad(&e0, 1, th_k1)) != ODEHIP_OK) return rc;
+      theta_sums(th_run, nullptr, th_run, nullptr, 0);
+      theta_sums(th_k1, nullptr, th_run, nullptr, 1);
+    }
     {
       const int which[4] = {0, 1, 2, 3}, lens[4] = {256, 256, 256, 256};
       float s4[4];
       if ((rc = fetch(4, which, lens, s4)) != ODEHIP_OK) return rc;
-      const float d0 = fmaxf(rms(s4[0]), rms(s4[1])), d1 = fmaxf(rms(s4[2]), rms(s4[3]));
+      float d0 = fmaxf(rms(s4[0]), rms(s4[1])), d1 = fmaxf(rms(s4[2]), rms(s4[3]));
+      if (mixed_norm) {
+        d0 = fmaxf(d0, theta_rms_max(g_adj_host + 8));
+        d1 = fmaxf(d1, theta_rms_max(g_adj_host + 8 + NT));
+      }
       const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
       float* k0y[1] = {ky[0]};
       float* k0a[1] = {ka[0]};
@@ -296,9 +400,16 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
       nfe += 1;
       sumsq(0, ky[1], ky[0], y_cur);
       sumsq(1, ka[1], ka[0], a_cur);
+      if (mixed_norm) {
+        const StageRef e1 = {slot, 1, L.xin(ws, slot, 1), 1.0f};
+        if ((rc = theta_wgrad(&e1, 1, th_kf)) != ODEHIP_OK) return rc;
+        theta_sums(th_kf, th_k1, th_run, nullptr, 0);
+      }
       float s2[2];
       if ((rc = fetch(2, which, lens, s2)) != ODEHIP_OK) return rc;
-      const float d2 = fmaxf(rms(s2[0]), rms(s2[1])) / h0;
+      float d2 = fmaxf(rms(s2[0]), rms(s2[1]));
+      if (mixed_norm) d2 = fmaxf(d2, theta_rms_max(g_adj_host + 8));
+      d2 /= h0;
       float h1;
       if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
       else h1 = powf(0.01f / fmaxf(d1, d2), 1.0f / 5.0f);
@@ -350,12 +461,23 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
         if ((rc = eval_aug(slot, s - 1, L.xin(ws, slot, s - 1), cy, ca)) != ODEHIP_OK) return rc;
       }
       nfe += 6;
+      StageRef ev[7];
+      ev[0] = StageRef{k1_slot, k1_stage, k1_x0, 0.0f};
+      for (int s = 1; s < 7; ++s) ev[s] = StageRef{slot, s, L.xin(ws, slot, s), 0.0f};
+      if (mixed_norm) {  // parameter block of this attempt: error estimate and increment, both linear in the seven stages
+        for (int s = 0; s < 7; ++s) ev[s].scale = h * (float)dp5::kCErr[s];
+        if ((rc = theta_wgrad(ev, 7, th_err)) != ODEHIP_OK) return rc;
+        for (int s = 0; s < 7; ++s) ev[s].scale = h * (float)dp5::kCSol[s];
+        if ((rc = theta_wgrad(ev, 7, th_inc)) != ODEHIP_OK) return rc;
+        theta_sums(th_err, nullptr, th_run, th_inc, 0);
+      }
       float e2[2];
       {
         const int which[2] = {4, 5}, lens[2] = {L.n_part, L.n_part};
         if ((rc = fetch(2, which, lens, e2)) != ODEHIP_OK) return rc;
       }
-      const float ratio = fmaxf(rms(e2[0]), rms(e2[1]));
+      float ratio = fmaxf(rms(e2[0]), rms(e2[1]));
+      if (mixed_norm) ratio = fmaxf(ratio, theta_rms_max(g_adj_host + 8));
       ODEHIP_REQUIRE(ratio == ratio, "odeint_adjoint_dopri5_backward: non-finite error ratio");
       const bool accept = ratio <= 1.0f;
       double dtn;
@@ -381,7 +503,14 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
         const float x = (float)((t_end - t_cur) / (t_new - t_cur));
         for (int s = 0; s < 7; ++s) w[s] = h * (float)dp5::dense_weight(s, (double)x);
       }
-      for (int s = 0; s < 7; ++s) {
+      if (mixed_norm) {  // the parameter block is integrated step by step (its running value enters the next tolerance)
+        if (final_step) {
+          for (int s = 0; s < 7; ++s) ev[s].scale = w[s];
+          if ((rc = theta_wgrad(ev, 7, th_inc)) != ODEHIP_OK) return rc;
+        }
+        hipLaunchKernelGGL(theta_add_kernel, dim3(64), dim3(256), 0, stream, th_run, th_inc, P);
+      }
+      for (int s = 0; s < 7 && !mixed_norm; ++s) {
         if (w[s] == 0.0f) continue;
         Entry e;
         e.scale = w[s];
@@ -413,7 +542,21 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
   rc = odehip_q4_to_nchw(a_cur, grad_z0_nchw, batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
 
-  // ---- a_theta: one wgrad launch per layer over every recorded stage evaluation
+  if (mixed_norm) {  // a_theta was integrated step by step: hand it out in the parameters' shapes
+    for (int l = 0; l < NL; ++l) {
+      ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_w[l], th_run + spans.off[2 * l], (size_t)(spans.off[2 * l + 1] - spans.off[2 * l]) * 4,
+                                      hipMemcpyDeviceToDevice, stream));
+      ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_b[l], th_run + spans.off[2 * l + 1], (size_t)(spans.off[2 * l + 2] - spans.off[2 * l + 1]) * 4,
+                                      hipMemcpyDeviceToDevice, stream));
+    }
+    if (stats_host) {
+      stats_host[0] = nfe;
+      stats_host[1] = n_accept;
+      stats_host[2] = n_reject;
+    }
+    return ODEHIP_OK;
+  }
+  // ---- seminorm: a_theta does not steer the steps, so ONE wgrad launch per layer over every recorded stage evaluation
   const int n_eval = (int)entries.size();
   WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
   float* slabs = L.p(ws, L.off_slab);

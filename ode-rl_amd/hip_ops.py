@@ -516,8 +516,8 @@ def odeint_adjoint_backward(stack, method, t, y_traj, grad_out):
     return gz0, gws, gbs
 
 
-def odeint_adjoint_dopri5_backward(stack, t, y_traj, grad_out, rtol, atol, max_accept=None, stats=None):
-    """torchdiffeq odeint_adjoint backward with method="dopri5" and the seminorm: (grad_z0, [grad_w...], [grad_b...]).
+def odeint_adjoint_dopri5_backward(stack, t, y_traj, grad_out, rtol, atol, max_accept=None, stats=None, mixed_norm=False):
+    """torchdiffeq odeint_adjoint backward with method="dopri5" (seminorm, or the default mixed norm): (grad_z0, [grad_w...], [grad_b...]).
     `stats`, if a dict, receives nfe / n_accept / n_reject of the backward solve."""
     require_device_tensor(grad_out, "grad_out")
     require_device_tensor(y_traj, "y_traj")
@@ -543,7 +543,7 @@ def odeint_adjoint_dopri5_backward(stack, t, y_traj, grad_out, rtol, atol, max_a
     st = (ctypes.c_int * 3)()
     _lib.check(lib.odehip_odeint_adjoint_dopri5_backward(ctypes.byref(desc), ctypes.byref(dg), tarr, n, b, float(rtol),
                                                          float(atol), _ptr(y_traj), _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr,
-                                                         int(max_accept), st, _ptr(ws), ws.numel(), _stream()))
+                                                         int(max_accept), int(bool(mixed_norm)), st, _ptr(ws), ws.numel(), _stream()))
     if stats is not None:
         stats.update(nfe=int(st[0]), n_accept=int(st[1]), n_reject=int(st[2]))
     return gz0, gws, gbs

@@ -30,8 +30,8 @@ def test_adjoint_option_errors(cuda):
     f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
     z0 = torch.randn(1, 64, 16, 16, device=cuda, requires_grad=True)
     t = torch.tensor([0.0, 0.5], dtype=torch.float64)
-    with pytest.raises(NotImplementedError):      # torchdiffeq's default (mixed) norm is declined, not silently replaced
-        ode_rl_amd.odeint_adjoint(f, z0, t, method="dopri5")
+    with pytest.raises(ValueError):               # unknown adjoint norm
+        ode_rl_amd.odeint_adjoint(f, z0, t, method="dopri5", adjoint_options={"norm": "bogus"})
     with pytest.raises(ValueError):
         ode_rl_amd.odeint_adjoint(f, z0, t, method="dopri5", adjoint_options={"norm": "seminorm", "bogus": 1})
     with pytest.raises(ValueError):
