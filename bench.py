@@ -54,6 +54,8 @@ def parse():
                    help="compute dtype of the 3x3 convs: f32 (headline, exact) or bf16 operands + fp32 accumulate/state (configs[4])")
     p.add_argument("--graph", action="store_true", help="diagnostic: replay the forward trajectory from a captured HIP graph")
     p.add_argument("--side-stream", action="store_true", help="diagnostic: run the timed region on a non-default stream")
+    p.add_argument("--adjoint-norm", default="seminorm", choices=["seminorm", "mixed"],
+                   help="dopri5 adjoint: seminorm, or torchdiffeq's default mixed norm (parameter block steers the steps)")
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,7 +166,7 @@ def main():
         f.zero_grad(set_to_none=False)
         if a.adjoint:
             o = ode_rl_amd.odeint_adjoint(f, zz, t, rtol=solver.odeint_rtol, atol=solver.odeint_atol, method=a.method,
-                                          adjoint_options={"norm": "seminorm"} if a.method == "dopri5" else None)
+                                          adjoint_options={"norm": a.adjoint_norm} if a.method == "dopri5" else None)
         else:
             o = solver(zz, t)
         o.backward(gout)
@@ -239,7 +241,7 @@ def main():
             "config": {"workload": f"{'ODEConvGRU' if a.shape == 'A' else 'VidODE'} latents z0 (B={a.batch},{C0},16,16) per GPU, T={T} output frames "
                                    f"({T - 1} intervals), " + (f"adaptive dopri5 rtol {solver.odeint_rtol:g} atol {solver.odeint_atol:g}" if a.method == "dopri5"
                                                                 else f"fixed-step {a.method} (3/8 rule)") + ", f = " + ("5x conv3x3(64->64)+ReLU" if a.shape == "A" else "conv3x3 128->64->64->128 +ReLU (VidODE)") + ", "
-                                   + (("forward + adjoint backward" + (" (seminorm)" if a.method == "dopri5" else "") if a.adjoint else
+                                   + (("forward + adjoint backward" + (f" ({a.adjoint_norm} norm)" if a.method == "dopri5" else "") if a.adjoint else
                                        "forward + backward (discretise-then-optimise)") if a.train else "forward only (BASELINE configs[1])"),
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}" + (", exact-global dopri5 step control" if (a.method == "dopri5" and a.global_step_control and world > 1)
                                                                      else (", per-shard dopri5 step control" if (a.method == "dopri5" and world > 1) else "")),
