@@ -31,7 +31,11 @@ def test_two_ranks_exact_global_dopri5_match_single_process(cuda, tmp_path):
     blob = {"state": f.state_dict(), "z0": z0, "gout": gout, "t": t, "rtol": 1e-4, "atol": 1e-5}
     torch.save(blob, tmp_path / "in.pt")
 
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    import socket
+    with socket.socket() as sk:   # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_gpu_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(tmp_path / f"out{r}.pt"), str(tmp_path / "in.pt")],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
