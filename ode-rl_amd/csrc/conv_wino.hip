@@ -51,7 +51,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rh = blockIdx.x & 1, ct = blockIdx.x >> 1, b = blockIdx.y;
+  // workgroups are dealt round-robin over the 8 XCDs in dispatch order: remap so that every XCD gets a CONTIGUOUS range of
+  // logical ids, i.e. the four workgroups of a sample (two co tiles x two image halves, which read the same input) share an L2
+  const int nwg = gridDim.x * gridDim.y;
+  int lid = blockIdx.x + gridDim.x * blockIdx.y;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
   const int r0 = rh * 8;
   constexpr int nchunk = NCHUNK;
   const bool skip = a.skip && *a.skip;  // adaptive solver finished while this launch was queued (uniform)
