@@ -32,10 +32,25 @@ constexpr int kFS = 144;                   // bytes per pixel of an activation t
 constexpr int kFTile = 18 * 18 * kFS;      // 46,656 B
 constexpr int kFUnit = 3 * 8192;           // one kernel row (3 taps) of one layer
 constexpr int kFStages = 3;
-constexpr int kFusedLds = kFTile + kFStages * kFUnit;
+constexpr int kFBias = ODEHIP_MAX_LAYERS * 64 * 4;  // every layer's bias, staged once (a global load per layer would sit in front of the ring's vmcnt waits)
+constexpr int kFusedLds = kFTile + kFStages * kFUnit + kFBias;
+
+// issued without the compiler's own s_waitcnt bookkeeping: the ring's counted waits cover it (see wait_younger)
+__device__ __forceinline__ f32x4 gload_untracked(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// n (wave-uniform) = vector-memory operations this wave issued AFTER the ring unit it is about to read: 3 (the next unit's
+// DMAs) + 8 per hidden-layer store set + 8 per prefetched mask set
+__device__ __forceinline__ void wait_younger(int n) {
+  if (n <= 3) wait_le<3>();
+  else if (n <= 11) wait_le<11>();
+  else wait_le<19>();
+}
 
 // DBG: diagnostic instantiation that honours the ablation flags in fa.last.debug (1 no weight DMA, 2 no MFMA and no operand
 // reads, 64 MFMA on constant operands); the production instantiation has no such branches in its inner loop.
@@ -44,6 +59,7 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const act = smem;
   char* const ring = smem + kFTile;
+  float* const bias_l = (float*)(smem + kFTile + kFStages * kFUnit);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
@@ -62,6 +78,7 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
   issue(0, 0);
   if (U > 1) issue(1, 1);
 
+  for (int i = threadIdx.x; i < NL * 64; i += 512) bias_l[i] = fa.bias[i >> 6] ? fa.bias[i >> 6][i & 63] : 0.0f;
   // zero border of the tile (68 pixels x 144 B), then the input: fp32 quads -> bf16
   for (int i = threadIdx.x; i < 68 * 9; i += 512) {
     const int p = i / 9, c16 = i % 9;
@@ -88,22 +105,42 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
   const int px = i32 & 15, pyl = i32 >> 4;
   const int P = (wave * 2 + pyl) * 16 + px;                       // pixel of this lane
   const char* const in = act + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + kq * 16;
-  bool drain = true;  // the next wait is a full one (first unit; after an epilogue that issued global loads / stores)
+  // The saved ReLU mask of a gradient chain is PREFETCHED at the start of its layer (32 VGPRs) and the hidden-layer stores are
+  // left in flight: both are counted in the ring's vmcnt waits instead of draining the ring at every layer boundary.
+  f32x4 mreg[8];
+  auto load_mask = [&](int e) {
+    const float* mk = fa.mask[e];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int Q = (i >> 2) * 8 + 2 * (i & 3) + kq;
+      mreg[i] = gload_untracked(mk + (((size_t)b * 16 + Q) * kPix + P) * 4);
+    }
+  };
   f32x16 acc0, acc1;
   for (int e = 0; e < NL; ++e) {
-    acc0 = bias_init(fa.bias[e], 0, kq);
-    acc1 = bias_init(fa.bias[e], 1, kq);
+    const bool has_mask = e < NL - 1 && fa.mask[e];
+    if (has_mask) load_mask(e);
+    // operations younger than this layer's first two units besides the next unit's DMAs (layer 0 drains at its first unit)
+    const int extra = e == 0 ? 0 : (fa.store[e - 1] ? 8 : 0) + (has_mask ? 8 : 0);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {  // unit = kernel row r of layer e; the ring stage is u mod 3 = r because units per layer = stages
       const int u = e * 3 + r;
       // unit u landed?  each wave has three DMAs per unit in flight, one unit issued beyond u (the last unit drains)
-      if (drain || u + 1 >= U) wait_le<0>(); else wait_le<3>();
-      drain = false;
+      if (u == 0 || u + 1 >= U) wait_le<0>(); else wait_younger(r < 2 ? 3 + extra : 3);
       // raw barrier (a __syncthreads() would drain vmcnt to 0 and serialise the ring): after lgkmcnt(0) this wave's LDS writes
       // (input staging, previous layer's epilogue) are complete; unit u is in LDS for every wave, every wave is done with u-1
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (u + 2 < U) issue(u + 2, (r + 2) % 3);
+      if (r == 0) {  // accumulators start from the bias: lane half kq holds channels 8g + 4kq .. +3 of each 32-channel half
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b0 = *(const f32x4*)(bias_l + e * 64 + 8 * g + 4 * kq);
+          const f32x4 b1 = *(const f32x4*)(bias_l + e * 64 + 32 + 8 * g + 4 * kq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc0[4 * g + j] = b0[j]; acc1[4 * g + j] = b1[j]; }
+        }
+      }
       if (DBG && (dbg & 2)) continue;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {  // tap (dy, dx) = (r - 1, c - 1)
@@ -132,7 +169,10 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float* st = fa.store[e];
-    const float* mk = fa.mask[e];
+    if (has_mask) {  // landed: the wait of kernel row 2 left only the next unit's DMAs in flight
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(mreg[i]));
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       const f32x16& acc = mb ? acc1 : acc0;
@@ -141,8 +181,8 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
         f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         const int Q = mb * 8 + 2 * g + kq;
         const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
-        if (mk) {
-          const f32x4 m = *(const f32x4*)(mk + off);
+        if (has_mask) {
+          const f32x4 m = mreg[mb * 4 + g];
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         } else {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -151,7 +191,6 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
         *(u32x2*)(act + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
       }
     }
-    if (st || mk) drain = true;  // global stores / loads were issued behind the ring DMAs: the next wait drains everything
   }
   // ---- last layer: the shared fused epilogue (stage combine, error partials, reverse-sweep targets, ...)
   epilogue(fa.last, acc0, b, 0, P, kq, wave, b * 16 + wave);

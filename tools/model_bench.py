@@ -19,7 +19,10 @@ def main():
     p.add_argument("--method", default="rk4")
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the hot-path convs")
+    p.add_argument("--only", default="all", choices=["all", "train"], help="'train': time the training step alone (profiling)")
+    p.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen search solvers for the convs either side of the path")
     a = p.parse_args()
+    torch.backends.cudnn.benchmark = a.miopen_find
     import ode_rl_amd
     from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
     if a.dtype == "bf16":
@@ -58,6 +61,10 @@ def main():
         optim.step()
 
     res = {"batch": a.batch, "frames_in": T, "frames_out": T, "method": a.method, "dtype": a.dtype}
+    if a.only == "train":
+        res["train_step_ms"] = timed(train, a.steps)
+        print(json.dumps(res), flush=True)
+        return
     res["forward_ms"] = timed(fwd, a.steps)
     res["train_step_ms"] = timed(train, a.steps)
     # parts of the forward
