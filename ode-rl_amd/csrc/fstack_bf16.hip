@@ -5,11 +5,13 @@
 // layers: the hidden activations live in LDS as bf16 (one [18][18][64] tile with a zero border, rewritten in place after a
 // barrier), the weights of all layers stream through a 3-stage LDS ring, one kernel row (3 taps, 24 KiB) per stage, counted
 // s_waitcnt + one raw barrier per row (four barriers per layer).
-//   wave w (8 waves, two per SIMD) owns image rows 2w, 2w+1 (32 pixels) and both 32-channel halves: 8 MFMAs
-//   (v_mfma_f32_32x32x16_bf16) per tap, the B operand shared by the two halves; 360 MFMAs per wave per 5-layer f.  (Four waves
-//   with twice the tile halve the weight-fragment reads but measured slower: with one wave per SIMD nothing hides the code
-//   around the per-tap barrier.)  Measured: 5.3 us per layer + 5 us per launch, of which 2.5 us per layer remain with the MFMAs
-//   and the weight DMA switched off -- the per-tap wait/barrier/issue sequence, not the matrix core, is the cost to attack next.
+//   wave w (8 waves, two per SIMD) owns one 32-channel half (w & 1) of four image rows (4 (w >> 1) .. +3 = two 32-pixel MFMA
+//   blocks): 8 MFMAs (v_mfma_f32_32x32x16_bf16) per tap, 360 per wave per 5-layer f.  The loop is LDS-read bound, not MFMA
+//   bound (0.96 us of MFMA per layer), so the tile is chosen for operand reuse: a weight fragment feeds both pixel blocks, and
+//   the activation fragments are read once per KERNEL ROW -- the dx = -1 / +1 taps are DPP row shifts of the centre fragment
+//   (an MFMA B-operand row of 16 lanes is 16 pixels of an image row; the lane shifted in from outside reads 0 = the padding):
+//   20 ds_read_b128 per wave per kernel row instead of 36.  Biases are staged in LDS once; the saved mask of a gradient chain
+//   is prefetched a layer ahead and the hidden-layer stores stay in flight, both counted in the ring's vmcnt waits.
 // The same kernel runs the input-gradient chain of the backward passes (transposed+flipped weights in execution order, the
 // ReLU replaced by the saved mask, every layer's fp32 gradient stored for the weight-gradient kernels) and can store the
 // hidden activations (fp32, for a later backward).  The last layer ends in the shared fused epilogue (conv_common.h).
@@ -21,6 +23,7 @@ namespace odehip {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -103,8 +106,9 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
 
   const int i32 = lane & 31, kq = lane >> 5;
   const int px = i32 & 15, pyl = i32 >> 4;
-  const int P = (wave * 2 + pyl) * 16 + px;                       // pixel of this lane
-  const char* const in = act + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + kq * 16;
+  const int mb = wave & 1, row0 = (wave >> 1) * 4 + pyl;          // 32-channel half; image row of this lane in pixel block 0
+  const int P0 = row0 * 16 + px, P1 = P0 + 32;                    // pixel of this lane in the two pixel blocks (rows +0, +2)
+  const char* const in = act + ((row0 + 1) * 18 + px + 1) * kFS + kq * 16;
   // The saved ReLU mask of a gradient chain is PREFETCHED at the start of its layer (32 VGPRs) and the hidden-layer stores are
   // left in flight: both are counted in the ring's vmcnt waits instead of draining the ring at every layer boundary.
   f32x4 mreg[8];
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
     const float* mk = fa.mask[e];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int Q = (i >> 2) * 8 + 2 * (i & 3) + kq;
-      mreg[i] = gload_untracked(mk + (((size_t)b * 16 + Q) * kPix + P) * 4);
+      const int Q = mb * 8 + 2 * (i & 3) + kq;
+      mreg[i] = gload_untracked(mk + (((size_t)b * 16 + Q) * kPix + ((i >> 2) ? P1 : P0)) * 4);
     }
   };
   f32x16 acc0, acc1;
@@ -132,35 +136,45 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (u + 2 < U) issue(u + 2, (r + 2) % 3);
-      if (r == 0) {  // accumulators start from the bias: lane half kq holds channels 8g + 4kq .. +3 of each 32-channel half
+      if (r == 0) {  // accumulators start from the bias: lane half kq holds channels 8g + 4kq .. +3 of its 32-channel half
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 b0 = *(const f32x4*)(bias_l + e * 64 + 8 * g + 4 * kq);
-          const f32x4 b1 = *(const f32x4*)(bias_l + e * 64 + 32 + 8 * g + 4 * kq);
+          const f32x4 b0 = *(const f32x4*)(bias_l + e * 64 + mb * 32 + 8 * g + 4 * kq);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { acc0[4 * g + j] = b0[j]; acc1[4 * g + j] = b1[j]; }
+          for (int j = 0; j < 4; ++j) { acc0[4 * g + j] = b0[j]; acc1[4 * g + j] = b0[j]; }
         }
       }
       if (DBG && (dbg & 2)) continue;
+      // activations of image rows + (r - 1), read ONCE per kernel row: the side taps are lane shifts inside the 16-pixel rows
+      // of the operand (DPP row_shr / row_shl; the lane shifted in from outside a row reads 0 = the zero padding)
+      u32x4 xc[2][4];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) xc[nb][cb] = *(const u32x4*)(in + ((r - 1) * 18 + nb * 36) * kFS + cb * 32);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {  // tap (dy, dx) = (r - 1, c - 1)
-        const char* wb = ring + r * kFUnit + c * 8192 + vw;
-        const char* xb = in + ((r - 1) * 18 + (c - 1)) * kFS;
-        bf16x8 xv[4], w0[4], w1[4];
+        const char* wb = ring + r * kFUnit + c * 8192 + mb * 1024 + vw;
+        bf16x8 w[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) w[cb] = *(const bf16x8*)(wb + cb * 2048);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-          xv[cb] = *(const bf16x8*)(xb + cb * 32);
-          w0[cb] = *(const bf16x8*)(wb + (cb * 2 + 0) * 1024);
-          w1[cb] = *(const bf16x8*)(wb + (cb * 2 + 1) * 1024);
-        }
-        if (DBG && (dbg & 64)) {
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) xv[cb] = w0[cb] = w1[cb] = w0[0];
-        }
+          for (int nb = 0; nb < 2; ++nb) {
+            u32x4 xs = xc[nb][cb];
+            if (c == 0) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[cb], xv[cb], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[cb], xv[cb], acc1, 0, 0, 0);
+              for (int j = 0; j < 4; ++j) xs[j] = __builtin_amdgcn_update_dpp(0u, xc[nb][cb][j], 0x111, 0xf, 0xf, true);  // row_shr:1
+            } else if (c == 2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) xs[j] = __builtin_amdgcn_update_dpp(0u, xc[nb][cb][j], 0x101, 0xf, 0xf, true);  // row_shl:1
+            }
+            bf16x8 xv = __builtin_bit_cast(bf16x8, xs);
+            if (DBG && (dbg & 64)) xv = w[0];
+            if (nb == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DBG && (dbg & 64) ? w[0] : w[cb], xv, acc0, 0, 0, 0);
+            else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DBG && (dbg & 64) ? w[0] : w[cb], xv, acc1, 0, 0, 0);
+          }
         }
       }
     }
@@ -174,27 +188,27 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
       for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(mreg[i]));
     }
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const f32x16& acc = mb ? acc1 : acc0;
+    for (int nb = 0; nb < 2; ++nb) {
+      const f32x16& acc = nb ? acc1 : acc0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         const int Q = mb * 8 + 2 * g + kq;
-        const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+        const size_t off = (((size_t)b * 16 + Q) * kPix + (nb ? P1 : P0)) * 4;
         if (has_mask) {
-          const f32x4 m = mreg[mb * 4 + g];
+          const f32x4 m = mreg[nb * 4 + g];
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         } else {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (st) *(f32x4*)(st + off) = v;
-        *(u32x2*)(act + ((wave * 2 + pyl + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+        *(u32x2*)(act + ((row0 + 2 * nb + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
       }
     }
   }
   // ---- last layer: the shared fused epilogue (stage combine, error partials, reverse-sweep targets, ...)
-  epilogue(fa.last, acc0, b, 0, P, kq, wave, b * 16 + wave);
-  epilogue(fa.last, acc1, b, 1, P, kq, wave, b * 16 + 8 + wave);
+  epilogue(fa.last, acc0, b, mb, P0, kq, wave, b * 16 + wave);
+  epilogue(fa.last, acc1, b, mb, P1, kq, wave, b * 16 + 8 + wave);
 }
 
 // fused image of executed layer `e`: [tap][cb][mb][h][co32][8]
