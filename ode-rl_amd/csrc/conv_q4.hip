@@ -222,8 +222,10 @@ __device__ __forceinline__ void wait_chunk(int younger) {
   wait_vmcnt<0>();
 }
 
-template <int KS, int MC, int NBUF>
-__global__ __launch_bounds__(256, 1) void conv_ring_kernel(const ConvArgs a) {
+// MINB = 2: a two-stage ring (62 KiB for 5x5) so that TWO workgroups share a CU -- with one wave per SIMD nothing else covers a
+// workgroup's ring fill, per-chunk barrier and epilogue; used when the grid has more workgroups than CUs anyway
+template <int KS, int MC, int NBUF, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void conv_ring_kernel(const ConvArgs a) {
   using C = RingCfg<KS, MC>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Stamps st(a);
@@ -369,16 +371,16 @@ static int launch_resident(const ConvArgs& a, hipStream_t stream) {
   return ODEHIP_OK;
 }
 
-template <int KS, int MC, int NBUF>
+template <int KS, int MC, int NBUF, int MINB = 1>
 static int launch_ring(const ConvArgs& a, hipStream_t stream) {
   using C = RingCfg<KS, MC>;
   static bool attr_set = false;
   const int nchunk = a.qin / (2 * MC);
   const int nbuf_alloc = (NBUF < nchunk) ? NBUF : nchunk;
   const size_t lds = (size_t)nbuf_alloc * C::STAGE_BYTES + 64;
-  int rc = prepare_kernel(conv_ring_kernel<KS, MC, NBUF>, lds, &attr_set);
+  int rc = prepare_kernel(conv_ring_kernel<KS, MC, NBUF, MINB>, lds, &attr_set);
   if (rc != ODEHIP_OK) return rc;
-  hipLaunchKernelGGL((conv_ring_kernel<KS, MC, NBUF>), dim3(a.batch * (a.qout / 8) * 2), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv_ring_kernel<KS, MC, NBUF, MINB>), dim3(a.batch * (a.qout / 8) * 2), dim3(256), lds, stream, a);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
@@ -423,6 +425,7 @@ int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
       const int rb = launch_bf16_5x5(a, stream);
       if (rb != 1) return rb;
     }
+    if (a.batch * (a.qout / 8) * 2 > 256 && !(g_debug_flags & 32)) return launch_ring<5, 1, 2, 2>(a, stream);
     return launch_ring<5, 1, 4>(a, stream);
   }
   if (ks == 1) {
