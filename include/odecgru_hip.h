@@ -315,6 +315,15 @@ int odehip_adam_step(float* const* params, const float* const* grads, float* con
                      const long long* numel, int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, void* stream);
 
+/* Moving-MNIST-shaped frames rendered on the device (replaces the host generator dataloader.py:47-103 + the normalisation of
+ * __getitem__ :217-218).  init: [batch][n_digits][4] doubles = x, y, v_x, v_y in the unit square (drawn by the host as
+ * dataloader.py:50-54 does); digit_ids: [batch][n_digits] indices into glyphs [n_glyphs][28][28] (uint8); lut256[v] =
+ * float32(v) / 255 - 0.5 evaluated in float32 as numpy does for the reference's float32 frames.  Frames 0..t_in-1 go to out_in (batch, t_in, 1, 64, 64), the rest to out_pred (batch, t_out, 1,
+ * 64, 64).  The digit ids are NOT range-checked on the device: the caller guarantees 0 <= id < n_glyphs. */
+int odehip_mmnist_render(const double* init, const int* digit_ids, const unsigned char* glyphs, int n_glyphs,
+                         const float* lut256, int batch, int n_digits, int t_in, int t_out, float* out_in, float* out_pred,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

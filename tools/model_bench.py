@@ -1,5 +1,5 @@
 """Context numbers: end-to-end ODEConvGRU forward and training step on one GPU, with the time of each
-part (conv encoder / ODEConvGRUCell / DiffEqSolver / conv decoder).  Synthetic Moving-MNIST-shaped frames.
+part (conv encoder / ODEConvGRUCell / DiffEqSolver / conv decoder).  Synthetic Moving-MNIST frames rendered on the device (ode-rl_amd/data.py).
   python tools/model_bench.py [--batch 64] [--frames 10] [--method rk4] [--steps 10]"""
 import argparse
 import json
@@ -34,8 +34,9 @@ def main():
                              z_sample=False)
     m = ODEConvGRU(opt, torch.device("cpu")).to(dev)
     T = a.frames
-    frames = torch.rand(a.batch, T, 1, 64, 64, device=dev)
-    truth = torch.rand(a.batch, T, 1, 64, 64, device=dev)
+    from ode_rl_amd.data import MovingMNISTSynthetic
+    batch = next(MovingMNISTSynthetic(T, T, num_objects=[2], batch_size=a.batch, device=dev, seed=0))  # rendered on the device
+    frames, truth = batch["observed_data"] + 0.5, batch["data_to_predict"] + 0.5                     # train_test.py:180
     ts = torch.arange(2 * T, dtype=torch.float64, device=dev) / (2 * T)
     bd = {"observed_tp": ts[:T], "tp_to_predict": ts[T:]}
     from ode_rl_amd.optim import FusedAdam
