@@ -315,6 +315,13 @@ int odehip_adam_step(float* const* params, const float* const* grads, float* con
                      const long long* numel, int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, void* stream);
 
+/* odehip_odeint_fixed runs a forward-only trajectory of a 64-channel fp32 stack as ONE persistent launch (the four workgroups of a
+ * sample hand layers to each other through L2 instead of through launch boundaries).  On by default
+ * (environment ODEHIP_PERSISTENT=0 turns it off); this switch is for A/B measurements and tests.  Returns the previous
+ * setting.  odehip_persistent_trajectory_launches: how many trajectories have taken that path in this process. */
+int odehip_set_persistent_trajectory(int enable);
+long long odehip_persistent_trajectory_launches(void);
+
 /* Moving-MNIST-shaped frames rendered on the device (replaces the host generator dataloader.py:47-103 + the normalisation of
  * __getitem__ :217-218).  init: [batch][n_digits][4] doubles = x, y, v_x, v_y in the unit square (drawn by the host as
  * dataloader.py:50-54 does); digit_ids: [batch][n_digits] indices into glyphs [n_glyphs][28][28] (uint8); lut256[v] =

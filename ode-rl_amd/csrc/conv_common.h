@@ -28,7 +28,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // ---- per-(channel quad Q, pixel P) epilogue: plain / ReLU store, Runge-Kutta stage combine (+ adaptive error
 // partial), ReLU-mask backward, reverse-sweep targets.  `v` is the conv output (bias included) of 4 channels.
-__device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P, f32x4 v, float& esum) {
+// nchw_override: persistent trajectory kernel only -- where this layer's NCHW result frame goes (its table cannot hold the
+// pointer: the output tensor changes from call to call)
+__device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P, f32x4 v, float& esum, float* nchw_override = nullptr) {
   const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
   if (a.combine == 0) {
     if (a.relu) {
@@ -78,8 +80,9 @@ __device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P
     if (m.out1) *(f32x4*)(m.out1 + off) = yv + sa * h;
     const f32x4 o2 = yv + sb * h;
     if (m.out2) *(f32x4*)(m.out2 + off) = o2;
-    if (m.out2_nchw) {
-      float* o = m.out2_nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
+    float* const nchw = nchw_override ? nchw_override : m.out2_nchw;
+    if (nchw) {
+      float* o = nchw + ((size_t)b * a.qout * 4 + Q * 4) * kPix + P;
       o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
     }
     if (m.err_partials) {

@@ -388,7 +388,15 @@ static int launch_ring(const ConvArgs& a, hipStream_t stream) {
 int g_debug_flags = 0;
 unsigned long long* g_debug_buf = nullptr;
 
+thread_local ConvRecorder* g_conv_recorder = nullptr;
+
 int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
+  if (g_conv_recorder) {
+    ConvRecorder* r = g_conv_recorder;
+    ODEHIP_REQUIRE(r->count < r->capacity, "conv recorder: more than %d layers", r->capacity);
+    r->items[r->count++] = a_in;
+    return ODEHIP_OK;
+  }
   ConvArgs a = a_in;
   a.debug = g_debug_flags;
   a.dbg = g_debug_buf;

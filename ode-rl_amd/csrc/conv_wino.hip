@@ -38,28 +38,68 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
   return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
-template <int NCHUNK, bool DBG>
-__global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __restrict__ p_src, const float* __restrict__ p_u,
-                                                              int p_qin, int p_qout, const ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// Hand-off between the layers of the persistent trajectory kernel (below): `done` is the sample's line of 16 words, one per
+// consumer wave of its four workgroups; a wave stores the number of layers it has finished (single writer per word: no
+// read-modify-write anywhere).  A layer's input is complete once all 16 words have reached `target`.
+struct PersistHook {
+  unsigned* done;
+  unsigned target;
+  int word0;           // first of this workgroup's four words
+  unsigned* abort_;    // device word: some wait of this launch has given up -- nobody waits any more
+  unsigned* host_err;  // mapped host word: a capped wait gave up (never expected; the kernel then finishes with wrong data)
+  bool fence;          // the sample's workgroups are NOT on one XCD: agent-scope release / acquire around the hand-off
+  float* nchw_base;    // base of the NCHW result tensor (the table holds offsets into it, in `dbg`)
+  unsigned long long* stamps;  // diagnostic (odehip_set_debug_buffer): 8 x 100 MHz timestamps of this layer, or null
+};
+__device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
+  if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
+}
+
+// a pointer the compiler must treat as wave-uniform (else every LDS-DMA on a descriptor built from it is wrapped in a
+// waterfall loop: measured 125 ns per DMA instruction instead of a few clocks)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void wait_done(const PersistHook& hk) {
+  int n = 0;
+  const int lane = threadIdx.x & 63;
+  while (!__all(lane >= 16 || __hip_atomic_load(hk.done + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++n & 1023) == 0) {
+      if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (n > (1 << 21)) {  // ~a second: partners lost -- report and stop ALL waiting rather than hang the device
+        __hip_atomic_store(hk.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *hk.host_err = 3;
+        break;
+      }
+    }
+  }
+  if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// One 3x3 layer for workgroup (sample b, 32-channel tile ct, image half rh).  PERSIST: called in a loop by
+// wino_persist_kernel -- the input tile is loaded past the per-CU cache (sc0 sc1: it was written by other CUs of this launch),
+// the first weight chunk is requested BEFORE waiting for the partners, and finished output is announced through hk.done.
+template <int NCHUNK, bool DBG, bool PERSIST>
+__device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, const float* __restrict__ p_u, int p_qin, const ConvArgs& a,
+                                           int b, int ct, int rh, char* smem, const PersistHook& hk) {
+  static_assert(!PERSIST || (NCHUNK % 2 == 0), "the layer-to-layer LDS hand-over assumes an even chunk count");
+  constexpr int kRawAux = PERSIST ? 16 : 0;  // sc1 (agent scope): never served from this CU's vector cache
   char* const Ub = smem;
   char* const Rb = smem + 2 * kWU;
   char* const Vb = smem + 2 * kWU + 2 * kWRaw;
-  (void)p_qout;
   Stamps st(a, (DBG && (a.debug & 16)) ? 256 : (DBG ? 0 : -1));  // debug 16: stamps from a producer wave instead of a consumer
   st.take(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // workgroups are dealt round-robin over the 8 XCDs in dispatch order: remap so that every XCD gets a CONTIGUOUS range of
-  // logical ids, i.e. the four workgroups of a sample (two co tiles x two image halves, which read the same input) share an L2
-  const int nwg = gridDim.x * gridDim.y;
-  int lid = blockIdx.x + gridDim.x * blockIdx.y;
-  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
-  const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
   const int r0 = rh * 8;
   constexpr int nchunk = NCHUNK;
-  const bool skip = a.skip && *a.skip;  // adaptive solver finished while this launch was queued (uniform)
+  const bool skip = !PERSIST && a.skip && *a.skip;  // adaptive solver finished while this launch was queued (uniform)
   const bool dbg_noprod = DBG && (a.debug & 1), dbg_nomfma = DBG && (a.debug & 2), dbg_notr = DBG && (a.debug & 32),
              dbg_nodma = DBG && (a.debug & 128);  // diagnostic ablations (tools/conv_microbench.py)
 
@@ -92,7 +132,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
     };
     auto issue_raw = [&](int c, int buf) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) dma16(rx, Rb + buf * kWRaw + (pw * 4 + p) * 1024, vr[p], (c * 4 + pw) * kQuadBytes);
+      for (int p = 0; p < 4; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, ODEHIP_LDS_PTR(Rb + buf * kWRaw + (pw * 4 + p) * 1024), 16, vr[p],
+                                                 (c * 4 + pw) * kQuadBytes, 0, kRawAux);
     };
     // input transform task: (half th, quad tq, tile tt) -> V rows 2*th, 2*th+1 of B^T d B.  Each producer wave
     // transforms the quad it DMA'd itself (tq = pw), so raw data needs no cross-wave hand-off: its own vmcnt suffices.
@@ -144,7 +186,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
 
     // DMA issue order per wave: raw_0 (4) | U_0 (8) | raw_1 (4) | then per iteration c: U_{c+1} (8) | raw_{c+2} (4).
     // Counted waits (vmcnt counts this wave's DMAs in issue order) leave the younger ones in flight.
-    if (!skip && !dbg_noprod) {
+    if (PERSIST) {
+      if (pw == 0) pstamp(hk, 0, lane);
+      issue_u(0, 0);                   // weights do not depend on the partners: requested before the wait
+      if (hk.target) wait_done(hk);    // the previous layer of this sample is complete in L2
+      if (pw == 0) pstamp(hk, 1, lane);
+      issue_raw(0, 0);
+      issue_raw(1, 1);
+      wait_vmcnt<4>();                 // U_0 and raw_0 landed (raw_1 still in flight)
+      if (pw == 0) pstamp(hk, 2, lane);
+      transform(0, 0);
+      if (pw == 0) pstamp(hk, 3, lane);
+    } else if (!skip && !dbg_noprod) {
       issue_raw(0, 0);
       issue_u(0, 0);
       if (nchunk > 1) issue_raw(1, 1);
@@ -184,10 +237,55 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   const int Q = ct * 8 + ch * 4 + kq;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias4 = *(const f32x4*)(a.bias + Q * 4);  // loaded now, used after the last MFMA
+  // PERSIST: every scalar the epilogue needs AND this lane's own operands of the stage combine (y, earlier k's: written by this
+  // very lane at least one layer ago) are fetched now, behind the wait for the first chunk -- after the last MFMA there is only
+  // arithmetic and stores left.  (Read from the table at that point they cost a scalar-cache miss each, one after the other.)
+  const int tile = thh * 16 + i16, oty = tile >> 3, otx = tile & 7;
+  int e_combine = 0, e_relu = 0, e_np = 0;
+  float* e_dst = nullptr;
+  float* e_kout = nullptr;
+  float* e_out1 = nullptr;
+  float* e_out2 = nullptr;
+  float* e_nchw = nullptr;
+  bool e_y = false;
+  float e_h = 1.0f, e_ks = 1.0f, e_c1c = 0.0f, e_c2c = 0.0f, e_c1[3] = {0.f, 0.f, 0.f}, e_c2[3] = {0.f, 0.f, 0.f};
+  f32x4 e_yv[4], e_kv[3][4];
+  if (PERSIST) {
+    e_combine = a.combine;
+    e_relu = a.relu;
+    e_dst = a.dst;
+    if (e_combine) {
+      const CombineArgs& m = a.cmb;
+      e_np = m.n_prev;
+      e_h = m.atol;  // the step size itself: the host resolves *h_ptr into this (otherwise unused) field of a persistent table
+      e_ks = m.k_scale;
+      e_c1c = m.c1[e_np];
+      e_c2c = m.c2[e_np];
+      e_kout = m.k_out;
+      e_out1 = m.out1;
+      e_out2 = m.out2;
+      e_nchw = a.dbg ? hk.nchw_base + ((size_t)a.dbg - 1) : nullptr;
+      e_y = m.y != nullptr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = (((size_t)b * 16 + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+        if (e_y) e_yv[q] = *(const f32x4*)(m.y + off);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) e_kv[j][q] = *(const f32x4*)(m.k_prev[j] + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        e_c1[j] = m.c1[j];
+        e_c2[j] = m.c2[j];
+      }
+    }
+  }
   st.take(2);
 #pragma unroll
   for (int c = 0; c < nchunk; ++c) {
     __builtin_amdgcn_s_barrier();  // [c]
+    if (PERSIST && c == 0 && wave == 0) pstamp(hk, 4, lane);
     if (!skip && !dbg_nomfma) {
       const char* u = Ub + (c & 1) * kWU + u_off;
       const char* v = Vb + (c & 1) * kWV + v_off;
@@ -224,6 +322,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
     }
   }
   if (skip) return;
+  if (PERSIST && wave == 0) pstamp(hk, 5, lane);
 
   // ---- output transform in registers: lane (tile i16 of half thh, row group kq) holds M_xi[co quad][tile] for all xi
   f32x4 S[2][4];
@@ -232,18 +331,151 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
     S[0][cI] = acc[0 * 4 + cI] + acc[1 * 4 + cI] + acc[2 * 4 + cI];
     S[1][cI] = pk_sub(pk_sub(acc[1 * 4 + cI], acc[2 * 4 + cI]), acc[3 * 4 + cI]);
   }
-  const int tile = thh * 16 + i16, oty = tile >> 3, otx = tile & 7;
   float esum = 0.0f;
+  // emit_quad's plain / stage-combine arithmetic on the operands fetched at the start of the layer (same expressions, same order)
+  auto emit_pre = [&](int q, int P, f32x4 v) {
+    const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+    if (!e_combine) {
+      if (e_relu) {
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+      }
+      *(f32x4*)(e_dst + off) = v;
+      return;
+    }
+    const f32x4 kc = v * e_ks;
+    if (e_kout) *(f32x4*)(e_kout + off) = kc;
+    if (e_y) {
+      f32x4 sa = kc * e_c1c;
+      f32x4 sb = kc * e_c2c;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < e_np) {
+          sa += e_kv[j][q] * e_c1[j];
+          sb += e_kv[j][q] * e_c2[j];
+        }
+      if (e_out1) *(f32x4*)(e_out1 + off) = e_yv[q] + sa * e_h;
+      const f32x4 o2 = e_yv[q] + sb * e_h;
+      if (e_out2) *(f32x4*)(e_out2 + off) = o2;
+      if (e_nchw) {
+        float* o = e_nchw + ((size_t)b * 64 + Q * 4) * kPix + P;
+        o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+      }
+    }
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const f32x4 y0 = S[i][0] + S[i][1] + S[i][2] + bias4;
     const f32x4 y1 = pk_sub(pk_sub(S[i][1] + bias4, S[i][2]), S[i][3]);
     const int P = (r0 + 2 * oty + i) * 16 + 2 * otx;
-    emit_quad(a, b, Q, P, y0, esum);
-    emit_quad(a, b, Q, P + 1, y1, esum);
+    if (PERSIST) {
+      emit_pre(2 * i, P, y0);
+      emit_pre(2 * i + 1, P + 1, y1);
+    } else {
+      emit_quad(a, b, Q, P, y0, esum);
+      emit_quad(a, b, Q, P + 1, y1, esum);
+    }
   }
-  finish_err(a, esum, wave);
-  st.flush(a);
+  if (PERSIST) {
+    // this wave's share of the layer is in L2 once its stores are acknowledged; then it counts itself in
+    if (wave == 0) pstamp(hk, 6, lane);
+    wait_vmcnt<0>();
+    if (wave == 0) pstamp(hk, 7, lane);
+    if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(hk.done + hk.word0 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    finish_err(a, esum, wave);
+    st.flush(a);
+  }
+}
+
+template <int NCHUNK, bool DBG>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __restrict__ p_src, const float* __restrict__ p_u,
+                                                              int p_qin, int p_qout, const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)p_qout;
+  // workgroups are dealt round-robin over the 8 XCDs in dispatch order: remap so that every XCD gets a CONTIGUOUS range of
+  // logical ids, i.e. the four workgroups of a sample (two co tiles x two image halves, which read the same input) share an L2
+  const int nwg = gridDim.x * gridDim.y;
+  int lid = blockIdx.x + gridDim.x * blockIdx.y;
+  if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
+  const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr};
+  wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
+}
+
+// ---- a whole fixed-grid trajectory in ONE launch (64-channel dynamics, forward only) ---------------------------------------
+// The ~2 us between dependent launches (and the cold start of every launch) is a fifth of a 10 us layer.  Here the 4
+// workgroups of a sample (2 channel tiles x 2 image halves) stay resident and walk the layer table themselves; between layers
+// they only wait for EACH OTHER (a per-sample counter), never for the grid.  What makes that cheap: with the XCD-aware id
+// mapping the four partners sit on ONE XCD, whose L2 is the coherence point of their stores -- so the hand-off needs no L2
+// write-back / invalidate, only (a) stores acknowledged (vmcnt(0)) before the counter is bumped and (b) input loads that skip
+// the per-CU cache.  The dispatch order is not an architectural guarantee, so every workgroup publishes the XCD it really
+// runs on (XCC_ID) and a group whose members differ falls back to agent-scope fences: slower, still correct.  All waits are
+// capped (-> *host_err) and the launch is cooperative (co-residency checked by the runtime), so a lost partner cannot hang.
+constexpr int kDoneStride = 64;
+struct PersistArgs {
+  const ConvArgs* table;  // one entry per layer of the whole trajectory, in execution order (library-owned device copy)
+  int n_layers, batch;
+  unsigned* done;         // [batch] counters, one per 256-byte line (kDoneStride words apart), zero on entry: counters of groups
+                          // on different XCDs must not share a cache line -- the line would bounce between the L2s on every bump
+  unsigned* xcc_of;       // [gridDim.x], zero on entry: XCC_ID + 1 of each logical workgroup; xcc_of[gridDim.x] = abort word
+  unsigned* host_err;
+  float* out_nchw;        // base of the (T,B,C,16,16) result: table entries carry offsets into it (in `dbg`)
+  unsigned long long* stamps;  // diagnostic: [64 layers][8] timestamps of logical workgroup 0, or null
+};
+
+__global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nwg = gridDim.x;  // a multiple of 32: every XCD holds whole groups of 4
+  const int lid = ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);
+  const int rh = lid & 1, ct = (lid >> 1) & 1, group = lid >> 2;
+  const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;  // HW_REG_XCC_ID[3:0]
+  if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool fence = false;
+  for (int p = 0; p < 4; ++p) {
+    unsigned v = 0;
+    int n = 0;
+    while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~3) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++n > (1 << 21)) {
+        __hip_atomic_store(pa.xcc_of + nwg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *pa.host_err = 2;
+        break;
+      }
+    }
+    fence |= (v != my_xcc);
+  }
+  fence = __builtin_amdgcn_readfirstlane(fence);
+  const int n_groups = nwg >> 2;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  for (int b = group; b < pa.batch; b += n_groups) {
+    // the table is read in place (uniform loads; a private copy would live in scratch) -- but a row that is first touched when
+    // it is needed costs a trip to HBM on the critical path of every layer, so: the producers' two pointers are fetched a layer
+    // ahead and the next row is pulled into L2 a layer ahead
+    const float* src = pa.table[0].src1;
+    const float* u = pa.table[0].w_wino;
+    for (int l = 0; l < pa.n_layers; ++l) {
+      // the table is constant for the whole launch: address space 4 lets the compiler fetch its fields with SCALAR loads (as a
+      // plain global pointer they become vector loads, each followed by vmcnt(0), because the kernel also stores to global memory)
+      typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
+      const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)pa.table + l);
+      const float* src_next = src;
+      const float* u_next = u;
+      if (l + 1 < pa.n_layers) {
+        src_next = pa.table[l + 1].src1;
+        u_next = pa.table[l + 1].w_wino;
+        if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
+          const unsigned v = __builtin_nontemporal_load((const unsigned*)&pa.table[l + 1] + threadIdx.x * 16);
+          asm volatile("" ::"v"(v));
+        }
+      }
+      const PersistHook hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence, pa.out_nchw,
+                              (pa.stamps && lid == 0 && b == group && l < 64) ? pa.stamps + l * 8 : nullptr};
+      wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, __builtin_amdgcn_readfirstlane(b), ct, rh, smem, hk);
+      src = src_next;
+      u = u_next;
+    }
+  }
 }
 
 template <int NCHUNK>
@@ -265,6 +497,23 @@ static int launch_wino_n(const ConvArgs& a, hipStream_t stream) {
   }
   hipLaunchKernelGGL((conv3x3_wino_kernel<NCHUNK, false>), grid, dim3(512), kWinoLds, stream, a.src1, a.w_wino, a.qin, a.qout, a);
   ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
+                        float* out_nchw, int grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  PersistArgs pa;
+  pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
+  pa.out_nchw = out_nchw;
+  pa.stamps = g_debug_buf;
+  void* args[] = {&pa};
+  // cooperative: the runtime refuses the launch unless all `grid` workgroups can be resident at once
+  ODEHIP_CHECK_HIP(hipLaunchCooperativeKernel((const void*)wino_persist_kernel, dim3(grid), dim3(512), args, kWinoLds, stream));
   return ODEHIP_OK;
 }
 

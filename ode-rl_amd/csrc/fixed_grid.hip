@@ -11,7 +11,11 @@
 //     Runge-Kutta bookkeeping (gy += gx, gk_j += c h gx, seed of the next interval) fused into the epilogue of
 //     the chain's last conv -- no standalone elementwise kernels;
 //   * all weight gradients are ONE launch per layer over all evaluations (wgrad.hip).
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
+#include <vector>
 
 #include "odehip_internal.h"
 
@@ -22,13 +26,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static int n_stages(int method) { return method == ODEHIP_RK4 ? 4 : (method == ODEHIP_MIDPOINT ? 2 : 1); }
 constexpr int kEsplit = 4;
+constexpr int kPersistDoneStride = 64;  // words between per-sample counters (= kDoneStride in conv_wino.hip)
+constexpr int kPersistGrid = 256;  // the persistent trajectory kernel holds every CU of an MI355X (one workgroup each)
 
 // Everything lives in the caller's workspace; this is the one place that knows where.
 struct FixedLayout {
   int T, B, C, S, NH, save;  // NH = hidden activations per evaluation of f (n_convs - 1)
   size_t st;                 // bytes of one (B,C,16,16) tensor
   size_t hid;                // bytes of one hidden activation (B,max_hidden,16,16)
-  size_t off_h, off_ping, off_pong, off_xs, off_k, off_y, off_xin, off_hid, off_gp, off_go, off_gy, off_g2, off_tab, off_slab, total;
+  size_t off_h, off_ping, off_pong, off_xs, off_k, off_y, off_xin, off_hid, off_gp, off_go, off_gy, off_g2, off_tab, off_slab, off_psync, total;
   FixedLayout(const odehip_convstack* f, int batch, int n_times, int method, int save_) {
     T = n_times; B = batch; C = f->channels[0]; S = n_stages(method); NH = f->n_convs - 1; save = save_;
     st = al256((size_t)B * C * kPix * 4);
@@ -44,6 +50,7 @@ struct FixedLayout {
     off_k = take(3 * st);
     off_y = take((size_t)T * st);
     off_xin = off_hid = off_gp = off_go = off_gy = off_g2 = off_tab = off_slab = 0;
+    off_psync = take(((size_t)B * kPersistDoneStride + kPersistGrid + 64) * 4);  // persistent kernel: done[B] (a line each) + xcc_of[grid] + abort
     if (save) {
       const size_t ne = (size_t)(T - 1) * S;
       off_xin = take(ne * st);             // stage inputs (slot s = 0 unused: it is y[n])
@@ -78,6 +85,79 @@ struct PtrPack {
 };
 __global__ void fill_u64_kernel(unsigned long long* dst, PtrPack p, int n) {
   if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+// ---- persistent trajectory launch (conv_wino.hip: wino_persist_kernel) -----------------------------------------------------
+// The layer sequence of a call is recorded (launch_conv under g_conv_recorder) and handed over as a device table.  Tables are
+// kept in a small LIBRARY-OWNED device cache keyed by content (the one allocation this library makes on its own: a caller's
+// workspace may be reused by other entry points between calls, which would silently invalidate a table parked there); a
+// steady loop re-uses its table without any upload.  Result pointers are stored as offsets so that a fresh output tensor per
+// call does not change the table.
+struct PersistState {
+  std::mutex mu;
+  struct Entry {
+    std::vector<char> host;
+    ConvArgs* dev = nullptr;
+    size_t cap = 0;
+    unsigned long long stamp = 0;
+  } tab[4];
+  unsigned long long clock = 0;
+  unsigned* host_err = nullptr;      // mapped, pinned: written by the kernel if a capped wait gives up
+  unsigned* host_err_dev = nullptr;
+  int enabled = -1;                  // -1 unknown, 0 off (env, device, or a failed launch), 1 on
+  long long launches = 0;
+};
+static PersistState g_persist;
+
+static bool persist_available() {
+  PersistState& P = g_persist;
+  if (P.enabled >= 0) return P.enabled == 1;
+  P.enabled = 0;
+  const char* env = getenv("ODEHIP_PERSISTENT");
+  if (env && env[0] == '0') return false;
+  int dev = 0, cus = 0, coop = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < kPersistGrid) return false;
+  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return false;
+  if (hipHostMalloc((void**)&P.host_err, 64, hipHostMallocMapped) != hipSuccess) return false;
+  *P.host_err = 0;
+  if (hipHostGetDevicePointer((void**)&P.host_err_dev, P.host_err, 0) != hipSuccess) return false;
+  P.enabled = 1;
+  return true;
+}
+
+static bool persist_layer_ok(const ConvArgs& a) {
+  return a.qin == 16 && a.q1 == 16 && a.qout == 16 && a.w_wino && !a.w_bf16 && !a.src2 && !a.skip && a.combine <= 1 &&
+         !(a.combine == 1 && a.cmb.err_partials);
+}
+
+// device copy of `items` (identical content -> the cached copy); null on failure
+static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t stream) {
+  PersistState& P = g_persist;
+  const size_t bytes = (size_t)n * sizeof(ConvArgs);
+  PersistState::Entry* lru = &P.tab[0];
+  for (auto& e : P.tab) {
+    if (e.dev && e.host.size() == bytes && memcmp(e.host.data(), items, bytes) == 0) {
+      e.stamp = ++P.clock;
+      return e.dev;
+    }
+    if (e.stamp < lru->stamp) lru = &e;
+  }
+  if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;  // a running launch may still read the entry being replaced
+  if (lru->cap < bytes) {
+    if (lru->dev) (void)hipFree(lru->dev);
+    lru->dev = nullptr;
+    lru->cap = 0;
+    if (hipMalloc((void**)&lru->dev, bytes) != hipSuccess) return nullptr;
+    lru->cap = bytes;
+  }
+  lru->host.assign((const char*)items, (const char*)items + bytes);
+  if (hipMemcpy(lru->dev, items, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    lru->host.clear();
+    return nullptr;
+  }
+  lru->stamp = ++P.clock;
+  return lru->dev;
 }
 
 static int check_common(const odehip_convstack* f, int method, const double* t_host, int n_times, int batch, const char* who) {
@@ -138,6 +218,18 @@ static int wgrad_all_layers(const odehip_convstack* f, const FixedLayout& L, voi
 
 using namespace odehip;
 
+extern "C" int odehip_set_persistent_trajectory(int enable) {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  const int was = g_persist.enabled != 0;
+  g_persist.enabled = enable ? (g_persist.host_err ? 1 : -1) : 0;
+  return was;
+}
+
+extern "C" long long odehip_persistent_trajectory_launches(void) {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  return g_persist.launches;
+}
+
 extern "C" size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int method,
                                                 int save_for_backward) {
   if (!f || batch <= 0 || n_times <= 0 || f->n_convs < 1) return 0;
@@ -172,7 +264,39 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   rc = upload_floats(hdev, hbuf, n_times - 1, stream);
   if (rc != ODEHIP_OK) return rc;
 
+  // One launch for the whole trajectory when the dynamics are the 64-channel fp32 stack and nothing is saved: the loop below
+  // then only RECORDS its layers.
+  bool persist = false;
+  std::vector<ConvArgs> rec_items;
+  ConvRecorder rec = {nullptr, 0, 0};
+  std::unique_lock<std::mutex> persist_lock(g_persist.mu, std::defer_lock);
+  if (!save_for_backward && f->ks == 3 && !f->w_fused && !g_debug_flags) {
+    bool ok = true;
+    for (int l = 0; l <= f->n_convs; ++l) ok = ok && f->channels[l] == 64;
+    for (int l = 0; l < f->n_convs; ++l) ok = ok && f->w_wino[l] && !f->w_bf16[l];
+    if (ok) {
+      persist_lock.lock();
+      if (persist_available()) {
+        if (*g_persist.host_err) {
+          const unsigned code = *g_persist.host_err;
+          *g_persist.host_err = 0;
+          g_persist.enabled = 0;
+          set_error("odeint_fixed: an earlier persistent launch gave up waiting for a partner workgroup (code %u); its result is "
+                    "invalid.  Persistent launches are now disabled for this process", code);
+          return ODEHIP_EINVAL;
+        }
+        persist = true;
+        rec_items.resize((size_t)(n_times - 1) * L.S * f->n_convs);
+        rec.items = rec_items.data();
+        rec.capacity = (int)rec_items.size();
+        g_conv_recorder = &rec;
+      } else {
+        persist_lock.unlock();
+      }
+    }
+  }
   float* hidv[ODEHIP_MAX_LAYERS];
+  auto enqueue_steps = [&]() -> int {
   for (int n = 0; n + 1 < n_times; ++n) {
     const float* y = L.y(ws, n);
     float* ynew = L.y(ws, n + 1);
@@ -240,6 +364,44 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       c.out2_nchw = ynew_nchw;
       if ((rc = run(3, xin(3), c)) != ODEHIP_OK) return rc;
     }
+  }
+  return ODEHIP_OK;
+  };
+  rc = enqueue_steps();
+  g_conv_recorder = nullptr;
+  if (rc != ODEHIP_OK || !persist) return rc;
+
+  bool all_ok = rec.count == rec.capacity;
+  for (int i = 0; i < rec.count && all_ok; ++i) all_ok = persist_layer_ok(rec.items[i]);
+  const ConvArgs* table = nullptr;
+  if (all_ok) {
+    for (int i = 0; i < rec.count; ++i) {  // result frames as offsets into out_nchw (the output tensor is new every call)
+      ConvArgs& a = rec.items[i];
+      a.dbg = nullptr;
+      if (a.combine == 1) a.cmb.atol = a.cmb.h_ptr ? hbuf[a.cmb.h_ptr - hdev] : 1.0f;  // h by value (read instead of *h_ptr)
+      if (a.combine == 1 && a.cmb.out2_nchw) {
+        a.dbg = (unsigned long long*)(uintptr_t)((size_t)(a.cmb.out2_nchw - out_nchw) + 1);
+        a.cmb.out2_nchw = nullptr;
+      }
+    }
+    table = persist_table(rec.items, rec.count, stream);
+  }
+  if (table) {
+    unsigned* sync = (unsigned*)L.p(ws, L.off_psync);
+    ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, ((size_t)batch * kPersistDoneStride + kPersistGrid + 64) * 4, stream));
+    rc = launch_wino_persist(table, rec.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, kPersistGrid, stream);
+    if (rc == ODEHIP_OK) {
+      ++g_persist.launches;
+      return rc;
+    }
+    g_persist.enabled = 0;  // e.g. the runtime refused the cooperative launch: fall through to one launch per layer, for good
+    (void)hipGetLastError();
+  }
+  for (int i = 0; i < rec.count; ++i) {  // replay the recorded layers as ordinary launches
+    ConvArgs a = rec.items[i];
+    if (a.dbg) a.cmb.out2_nchw = out_nchw + ((size_t)(uintptr_t)a.dbg - 1);
+    a.dbg = nullptr;
+    if ((rc = launch_conv(a, f->ks, stream)) != ODEHIP_OK) return rc;
   }
   return ODEHIP_OK;
 }

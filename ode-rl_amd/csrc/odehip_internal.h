@@ -96,6 +96,15 @@ struct ConvArgs {
 };
 
 int launch_conv(const ConvArgs& a, int ks, hipStream_t stream);
+// While non-null (set by a driver on its own thread), launch_conv() appends its argument here INSTEAD of launching: the driver
+// collects the layer sequence of a whole trajectory and hands it to the persistent kernel (conv_wino.hip).
+struct ConvRecorder {
+  ConvArgs* items;
+  int count, capacity;
+};
+extern thread_local ConvRecorder* g_conv_recorder;
+int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
+                        float* out_nchw, int grid, hipStream_t stream);
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_bf16(const ConvArgs& a, hipStream_t stream);
 int launch_bf16_5x5(const ConvArgs& a, hipStream_t stream);

@@ -3,6 +3,8 @@
 Tolerances (fp32, stated per north_star): rel-L2 <= 1e-4 for trajectories (observed ~1e-6);
 f(y) alone <= 5e-6.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -210,3 +212,31 @@ def test_host_time_cache_never_serves_a_recycled_address(cuda):
         b = ode_rl_amd.odeint(f, z0, ts[3:], method="rk4")[-1]
     assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
     assert torch.equal(a, outs[0]) and torch.equal(b, outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,batch,n_times", [("rk4", 64, 10), ("rk4", 4, 6), ("midpoint", 70, 5), ("euler", 128, 4)])
+def test_persistent_trajectory_is_bit_identical_to_per_layer_launches(cuda, method, batch, n_times):
+    """One persistent launch per trajectory (workgroups of a sample hand layers over through L2) against one launch per layer:
+    same arithmetic in the same order, so the results must be equal bit for bit -- also for batches that are not a multiple
+    of the 64 resident groups and for several passes per group."""
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    torch.manual_seed(5)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
+    z0 = torch.randn(batch, 64, 16, 16, device=cuda) * 0.5
+    t = torch.arange(n_times, 2 * n_times, dtype=torch.float64, device=cuda) / (2 * n_times)
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        with torch.no_grad():
+            ref = ode_rl_amd.odeint(f, z0, t, method=method)
+            lib.odehip_set_persistent_trajectory(1)
+            n0 = lib.odehip_persistent_trajectory_launches()
+            for _ in range(3):  # the cached table and the zeroed counters must serve repeated calls
+                out = ode_rl_amd.odeint(f, z0, t, method=method)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref)
+            if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+                assert lib.odehip_persistent_trajectory_launches() == n0 + 3, "the persistent path did not run"
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
