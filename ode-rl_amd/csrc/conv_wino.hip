@@ -71,7 +71,7 @@ __device__ __forceinline__ void wait_done(const PersistHook& hk) {
     __builtin_amdgcn_s_sleep(1);
     if ((++n & 1023) == 0) {
       if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-      if (n > (1 << 21)) {  // ~a second: partners lost -- report and stop ALL waiting rather than hang the device
+      if (n > (1 << 23)) {  // seconds: partners lost -- report and stop ALL waiting rather than hang the device
         __hip_atomic_store(hk.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *hk.host_err = 3;
         break;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs 
     int n = 0;
     while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~3) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
       __builtin_amdgcn_s_sleep(2);
-      if (++n > (1 << 21)) {
+      if (++n > (1 << 23)) {
         __hip_atomic_store(pa.xcc_of + nwg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *pa.host_err = 2;
         break;
@@ -448,7 +448,10 @@ __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs 
   fence = __builtin_amdgcn_readfirstlane(fence);
   const int n_groups = nwg >> 2;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  for (int b = group; b < pa.batch; b += n_groups) {
+  // A group walks TWO samples at a time, layer by layer in turn (when the batch gives it more than one): the hand-off latency of
+  // one sample's layer (stores acknowledged -> flags seen -> next input tile loaded) is then covered by the other sample's layer.
+  for (int b = group; b < pa.batch; b += 2 * n_groups) {
+    const int n_interleaved = b + n_groups < pa.batch ? 2 : 1;
     // the table is read in place (uniform loads; a private copy would live in scratch) -- but a row that is first touched when
     // it is needed costs a trip to HBM on the critical path of every layer, so: the producers' two pointers are fetched a layer
     // ahead and the next row is pulled into L2 a layer ahead
@@ -469,9 +472,13 @@ __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs 
           asm volatile("" ::"v"(v));
         }
       }
-      const PersistHook hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence, pa.out_nchw,
-                              (pa.stamps && lid == 0 && b == group && l < 64) ? pa.stamps + l * 8 : nullptr};
-      wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, __builtin_amdgcn_readfirstlane(b), ct, rh, smem, hk);
+#pragma unroll 1
+      for (int s = 0; s < n_interleaved; ++s) {
+        const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
+        const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence, pa.out_nchw,
+                                (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr};
+        wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
+      }
       src = src_next;
       u = u_next;
     }

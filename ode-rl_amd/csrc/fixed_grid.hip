@@ -264,13 +264,13 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   rc = upload_floats(hdev, hbuf, n_times - 1, stream);
   if (rc != ODEHIP_OK) return rc;
 
-  // One launch for the whole trajectory when the dynamics are the 64-channel fp32 stack and nothing is saved: the loop below
-  // then only RECORDS its layers.
+  // One launch for the whole trajectory when the dynamics are the 64-channel fp32 stack: the loop below then only RECORDS its
+  // layers.
   bool persist = false;
   std::vector<ConvArgs> rec_items;
   ConvRecorder rec = {nullptr, 0, 0};
   std::unique_lock<std::mutex> persist_lock(g_persist.mu, std::defer_lock);
-  if (!save_for_backward && f->ks == 3 && !f->w_fused && !g_debug_flags) {
+  if (f->ks == 3 && !f->w_fused && !g_debug_flags) {  // (with save_for_backward only the destinations of the hidden layers differ)
     bool ok = true;
     for (int l = 0; l <= f->n_convs; ++l) ok = ok && f->channels[l] == 64;
     for (int l = 0; l < f->n_convs; ++l) ok = ok && f->w_wino[l] && !f->w_bf16[l];
