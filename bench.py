@@ -6,7 +6,8 @@ Inputs are resident in HBM before the timed region.  With --gpus N every rank in
 (weak scaling, no data-path collective: samples are independent under a fixed-grid solver).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- dominant kernel (conv3x3_wino_kernel<4>: Winograd F(2x2,3x3) on exact-fp32 MFMA): algorithmic FLOP per launch /
+  roofline     -- dominant kernel (wino_persist_kernel: the whole trajectory, Winograd F(2x2,3x3) on exact-fp32 MFMA, in one
+                  launch; conv3x3_wino_kernel<4> per layer when the persistent path is off): algorithmic FLOP per launch /
                   average launch duration measured with HIP events over the timed region;
   cpu_baseline -- the oracle (CPU restatement of torchdiffeq 0.2.1 on torch-CPU convs) timed on this
                   box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
@@ -197,6 +198,7 @@ def main():
         out = step()
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    persist0 = ode_rl_amd._lib.load().odehip_persistent_trajectory_launches()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
@@ -228,6 +230,15 @@ def main():
         # ALGORITHMIC work of one 64->64 3x3 layer over the batch (direct-convolution FLOPs); the
         # Winograd kernel executes 2.25x fewer MFMA FLOPs for it, so `frac` is algorithmic throughput over the MFMA peak
         flop_per_launch = conv_flops(chans, a.batch) / n_convs      # average layer of f (A: every layer is 64 -> 64)
+        kernel = "conv3x3_wino_kernel<4>" if a.dtype == "f32" else "conv3x3_bf16_kernel<4>"
+        persistent = ode_rl_amd._lib.load().odehip_persistent_trajectory_launches() - persist0
+        if persistent == a.steps and not a.train:
+            # the whole trajectory is ONE launch of wino_persist_kernel: its algorithmic work = every layer of every f evaluation
+            # (339.7 MFLOP per latent frame for A, T=10); duration = the timed region / steps (the copy of
+            # z0, the layout kernel and two tiny fills ride along: < 2 %)
+            kernel = "wino_persist_kernel"
+            flop_per_launch = conv_flops(chans, a.batch) * nfe_per_step
+            launches = a.steps
         per_launch_s = dev_ms * 1e-3 / launches                      # HIP events, incl. inter-kernel gaps
         achieved = flop_per_launch / per_launch_s / 1e12
         res = {
@@ -247,7 +258,7 @@ def main():
                                                                      else (", per-shard dopri5 step control" if (a.method == "dopri5" and world > 1) else "")),
                        "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None,
                        "n_accept": int(ode_rl_amd.last_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_kernel<4>" if a.dtype == "f32" else "conv3x3_bf16_kernel<4>",
+            "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
                          "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A") else None,

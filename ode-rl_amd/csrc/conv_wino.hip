@@ -411,7 +411,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
 // write-back / invalidate, only (a) stores acknowledged (vmcnt(0)) before the counter is bumped and (b) input loads that skip
 // the per-CU cache.  The dispatch order is not an architectural guarantee, so every workgroup publishes the XCD it really
 // runs on (XCC_ID) and a group whose members differ falls back to agent-scope fences: slower, still correct.  All waits are
-// capped (-> *host_err) and the launch is cooperative (co-residency checked by the runtime), so a lost partner cannot hang.
+// capped (-> *host_err; the grid is one workgroup per CU and the occupancy is checked before the first launch), so a lost
+// partner cannot hang the device.
 constexpr int kDoneStride = 64;
 struct PersistArgs {
   const ConvArgs* table;  // one entry per layer of the whole trajectory, in execution order (library-owned device copy)
@@ -512,15 +513,20 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   static bool attr_set = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // every workgroup must be resident at once: one per CU (160 KiB of LDS each), `grid` <= number of CUs (checked by the caller)
+    int per_cu = 0;
+    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist_kernel, 512, kWinoLds));
+    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist: the kernel does not fit a CU");
     attr_set = true;
   }
   PersistArgs pa;
   pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
   pa.out_nchw = out_nchw;
   pa.stamps = g_debug_buf;
-  void* args[] = {&pa};
-  // cooperative: the runtime refuses the launch unless all `grid` workgroups can be resident at once
-  ODEHIP_CHECK_HIP(hipLaunchCooperativeKernel((const void*)wino_persist_kernel, dim3(grid), dim3(512), args, kWinoLds, stream));
+  // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
+  // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
+  hipLaunchKernelGGL(wino_persist_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
 

@@ -115,10 +115,9 @@ static bool persist_available() {
   P.enabled = 0;
   const char* env = getenv("ODEHIP_PERSISTENT");
   if (env && env[0] == '0') return false;
-  int dev = 0, cus = 0, coop = 0;
+  int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < kPersistGrid) return false;
-  if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop) return false;
   if (hipHostMalloc((void**)&P.host_err, 64, hipHostMallocMapped) != hipSuccess) return false;
   *P.host_err = 0;
   if (hipHostGetDevicePointer((void**)&P.host_err_dev, P.host_err, 0) != hipSuccess) return false;
@@ -394,7 +393,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
       ++g_persist.launches;
       return rc;
     }
-    g_persist.enabled = 0;  // e.g. the runtime refused the cooperative launch: fall through to one launch per layer, for good
+    g_persist.enabled = 0;  // the launch was refused: fall through to one launch per layer, for good
     (void)hipGetLastError();
   }
   for (int i = 0; i < rec.count; ++i) {  // replay the recorded layers as ordinary launches

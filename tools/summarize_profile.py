@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "conv3x3_wino_kernel<4"
+KERNEL = None  # the dominant kernel of the forward run (first row of its kernel stats)
 
 
 def stats(path):
@@ -23,6 +23,8 @@ def main():
     trn = glob.glob(os.path.join(src, "train", "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(fwd, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     shutil.copy(trn, os.path.join(dst, f"{tag}_train_kernel_stats.csv"))
+    global KERNEL
+    KERNEL = stats(fwd)[0]["Name"].split("(")[0]
     pmc = {}
     for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         acc = {}
@@ -36,13 +38,18 @@ def main():
                    "--no-cpu-baseline ; separate --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*); train: bench.py --train",
         "units": "FETCH_SIZE/WRITE_SIZE in KiB per launch; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of a "
                  "wide coalesced 16 B/lane stream -> doubled",
-        "algorithmic_bytes_per_launch": 8536064,
-        "algorithmic_flop_per_launch": 1207959552,
-        "executed_mfma_flop_per_launch": 536870912,
+        "dominant_kernel": KERNEL,
     }
+    if "persist" in KERNEL:  # one launch = the whole trajectory (B=64, T=10, rk4: 180 layers)
+        notes.update({"algorithmic_flop_per_launch": 180 * 1207959552, "executed_mfma_flop_per_launch": 180 * 536870912,
+                      "algorithmic_bytes_per_launch_fused_ideal": 64 * 11 * 65536 + 5 * 147712,
+                      "algorithmic_bytes_per_launch_per_layer_io": 180 * 8536064})
+    else:
+        notes.update({"algorithmic_bytes_per_launch": 8536064, "algorithmic_flop_per_launch": 1207959552,
+                      "executed_mfma_flop_per_launch": 536870912})
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         notes["hbm_bytes_per_launch"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-    out = {"forward_kernel_stats": stats(fwd)[:12], "train_kernel_stats": stats(trn)[:16], "pmc_conv3x3_wino_per_launch": pmc,
+    out = {"forward_kernel_stats": stats(fwd)[:12], "train_kernel_stats": stats(trn)[:16], "pmc_dominant_kernel_per_launch": pmc,
            "notes": notes}
     json.dump(out, open(os.path.join(dst, f"{tag}_rocprof_summary.json"), "w"), indent=1)
     line = [l for l in open(os.path.join(src, "fwd.log")) if l.startswith("{")]
