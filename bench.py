@@ -263,7 +263,10 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
                          "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A") else None,
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
-                         "launches_timed": launches},
+                         "launches_timed": launches,
+                         # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the fp32 Winograd kernels execute 2.25x fewer
+                         # on the matrix cores, so frac can exceed 1 -- the share of the MFMA peak actually executed is:
+                         "executed_mfma_frac": (achieved / 2.25 / PEAK_FP32_MFMA_TFLOPS) if a.dtype == "f32" else None},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(state, z0_cpu, t_cpu, a.method, a.cpu_seconds)
