@@ -254,7 +254,16 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     e_combine = a.combine;
     e_relu = a.relu;
     e_dst = a.dst;
-    if (e_combine) {
+    if (e_combine == 2) {  // ReLU-mask backward layer: dst = scale * acc * (mask > 0); the mask values are fetched now
+      const BwdArgs& w = a.bwd;
+      e_ks = w.sc_c + w.sc_h * a.cmb.atol;  // atol = the step size, resolved by the host
+      e_y = w.mask_src != nullptr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = (((size_t)b * 16 + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+        if (e_y) e_yv[q] = *(const f32x4*)(w.mask_src + off);
+      }
+    } else if (e_combine == 1) {
       const CombineArgs& m = a.cmb;
       e_np = m.n_prev;
       e_h = m.atol;  // the step size itself: the host resolves *h_ptr into this (otherwise unused) field of a persistent table
@@ -340,6 +349,20 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
         v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
       }
       *(f32x4*)(e_dst + off) = v;
+      return;
+    }
+    if (e_combine == 2) {
+      v *= e_ks;
+      if (e_y) {
+        const f32x4 mk = e_yv[q];
+        v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f;
+        v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+      }
+      *(f32x4*)(e_dst + off) = v;
+      return;
+    }
+    if (e_combine == 3) {  // reverse-sweep targets: the shared epilogue, read from the table
+      emit_quad(a, b, Q, P, v, esum);
       return;
     }
     const f32x4 kc = v * e_ks;

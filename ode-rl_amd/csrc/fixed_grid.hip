@@ -126,7 +126,7 @@ static bool persist_available() {
 }
 
 static bool persist_layer_ok(const ConvArgs& a) {
-  return a.qin == 16 && a.q1 == 16 && a.qout == 16 && a.w_wino && !a.w_bf16 && !a.src2 && !a.skip && a.combine <= 1 &&
+  return a.qin == 16 && a.q1 == 16 && a.qout == 16 && a.w_wino && !a.w_bf16 && !a.src2 && !a.skip && a.combine >= 0 && a.combine <= 3 &&
          !(a.combine == 1 && a.cmb.err_partials);
 }
 
@@ -158,6 +158,92 @@ static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t s
   lru->stamp = ++P.clock;
   return lru->dev;
 }
+
+// Records the conv launches of a driver between begin() and finish(); finish() runs them as one persistent launch, or replays
+// them one by one when the persistent path is unavailable.  Layers other than launch_conv calls must not be enqueued in between.
+class PersistScope {
+ public:
+  PersistScope() : lock_(g_persist.mu, std::defer_lock) {}
+  ~PersistScope() { g_conv_recorder = nullptr; }
+  // rc != OK: a sticky error of an earlier launch was found.  active(): the recorder is on.
+  int begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers) {
+    if (f->ks != 3 || f->w_fused || (f2 && f2->w_fused) || g_debug_flags) return ODEHIP_OK;
+    for (int l = 0; l <= f->n_convs; ++l)
+      if (f->channels[l] != 64) return ODEHIP_OK;
+    for (int l = 0; l < f->n_convs; ++l)
+      if (!f->w_wino[l] || f->w_bf16[l] || (f2 && (!f2->w_wino[l] || f2->w_bf16[l]))) return ODEHIP_OK;
+    lock_.lock();
+    if (!persist_available()) {
+      lock_.unlock();
+      return ODEHIP_OK;
+    }
+    if (*g_persist.host_err) {
+      const unsigned code = *g_persist.host_err;
+      *g_persist.host_err = 0;
+      g_persist.enabled = 0;
+      set_error("an earlier persistent launch gave up waiting for a partner workgroup (code %u); its result is invalid.  "
+                "Persistent launches are now disabled for this process", code);
+      return ODEHIP_EINVAL;
+    }
+    items_.resize((size_t)max_layers);
+    rec_.items = items_.data();
+    rec_.count = 0;
+    rec_.capacity = max_layers;
+    g_conv_recorder = &rec_;
+    active_ = true;
+    return ODEHIP_OK;
+  }
+  bool active() const { return active_; }
+  // hbuf / hdev: host copy and device array of the step sizes (the table gets h by value); out_nchw may be null
+  int finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream) {
+    g_conv_recorder = nullptr;
+    if (!active_) return ODEHIP_OK;
+    active_ = false;
+    bool all_ok = rec_.count > 0;
+    for (int i = 0; i < rec_.count && all_ok; ++i) all_ok = persist_layer_ok(rec_.items[i]);
+    const ConvArgs* table = nullptr;
+    if (all_ok) {
+      for (int i = 0; i < rec_.count; ++i) {
+        ConvArgs& a = rec_.items[i];
+        a.dbg = nullptr;
+        // h by value, in a field no fixed-grid layer uses (read instead of *h_ptr)
+        const float* hp = a.combine == 1 ? a.cmb.h_ptr : (a.combine >= 2 ? a.bwd.h_ptr : nullptr);
+        a.cmb.atol = hp ? hbuf[hp - hdev] : (a.combine == 1 ? 1.0f : 0.0f);
+        if (a.combine == 1 && a.cmb.out2_nchw) {  // result frames as offsets: the output tensor is new every call
+          a.dbg = (unsigned long long*)(uintptr_t)((size_t)(a.cmb.out2_nchw - out_nchw) + 1);
+          a.cmb.out2_nchw = nullptr;
+        }
+      }
+      table = persist_table(rec_.items, rec_.count, stream);
+    }
+    int rc;
+    if (table) {
+      ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, ((size_t)batch * kPersistDoneStride + kPersistGrid + 64) * 4, stream));
+      rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
+                               kPersistGrid, stream);
+      if (rc == ODEHIP_OK) {
+        ++g_persist.launches;
+        return rc;
+      }
+      g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
+      (void)hipGetLastError();
+    }
+    for (int i = 0; i < rec_.count; ++i) {  // replay the recorded layers as ordinary launches
+      ConvArgs a = rec_.items[i];
+      if (a.dbg) a.cmb.out2_nchw = out_nchw + ((size_t)(uintptr_t)a.dbg - 1);
+      a.dbg = nullptr;
+      if (a.combine != 1) a.cmb.atol = 0.0f;
+      if ((rc = launch_conv(a, ks, stream)) != ODEHIP_OK) return rc;
+    }
+    return ODEHIP_OK;
+  }
+
+ private:
+  std::unique_lock<std::mutex> lock_;
+  std::vector<ConvArgs> items_;
+  ConvRecorder rec_ = {nullptr, 0, 0};
+  bool active_ = false;
+};
 
 static int check_common(const odehip_convstack* f, int method, const double* t_host, int n_times, int batch, const char* who) {
   int rc = check_stack(f);
@@ -264,36 +350,9 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   if (rc != ODEHIP_OK) return rc;
 
   // One launch for the whole trajectory when the dynamics are the 64-channel fp32 stack: the loop below then only RECORDS its
-  // layers.
-  bool persist = false;
-  std::vector<ConvArgs> rec_items;
-  ConvRecorder rec = {nullptr, 0, 0};
-  std::unique_lock<std::mutex> persist_lock(g_persist.mu, std::defer_lock);
-  if (f->ks == 3 && !f->w_fused && !g_debug_flags) {  // (with save_for_backward only the destinations of the hidden layers differ)
-    bool ok = true;
-    for (int l = 0; l <= f->n_convs; ++l) ok = ok && f->channels[l] == 64;
-    for (int l = 0; l < f->n_convs; ++l) ok = ok && f->w_wino[l] && !f->w_bf16[l];
-    if (ok) {
-      persist_lock.lock();
-      if (persist_available()) {
-        if (*g_persist.host_err) {
-          const unsigned code = *g_persist.host_err;
-          *g_persist.host_err = 0;
-          g_persist.enabled = 0;
-          set_error("odeint_fixed: an earlier persistent launch gave up waiting for a partner workgroup (code %u); its result is "
-                    "invalid.  Persistent launches are now disabled for this process", code);
-          return ODEHIP_EINVAL;
-        }
-        persist = true;
-        rec_items.resize((size_t)(n_times - 1) * L.S * f->n_convs);
-        rec.items = rec_items.data();
-        rec.capacity = (int)rec_items.size();
-        g_conv_recorder = &rec;
-      } else {
-        persist_lock.unlock();
-      }
-    }
-  }
+  // layers (with save_for_backward only the destinations of the hidden layers differ).
+  PersistScope persist;
+  if ((rc = persist.begin(f, nullptr, (n_times - 1) * L.S * f->n_convs)) != ODEHIP_OK) return rc;
   float* hidv[ODEHIP_MAX_LAYERS];
   auto enqueue_steps = [&]() -> int {
   for (int n = 0; n + 1 < n_times; ++n) {
@@ -367,42 +426,8 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   return ODEHIP_OK;
   };
   rc = enqueue_steps();
-  g_conv_recorder = nullptr;
-  if (rc != ODEHIP_OK || !persist) return rc;
-
-  bool all_ok = rec.count == rec.capacity;
-  for (int i = 0; i < rec.count && all_ok; ++i) all_ok = persist_layer_ok(rec.items[i]);
-  const ConvArgs* table = nullptr;
-  if (all_ok) {
-    for (int i = 0; i < rec.count; ++i) {  // result frames as offsets into out_nchw (the output tensor is new every call)
-      ConvArgs& a = rec.items[i];
-      a.dbg = nullptr;
-      if (a.combine == 1) a.cmb.atol = a.cmb.h_ptr ? hbuf[a.cmb.h_ptr - hdev] : 1.0f;  // h by value (read instead of *h_ptr)
-      if (a.combine == 1 && a.cmb.out2_nchw) {
-        a.dbg = (unsigned long long*)(uintptr_t)((size_t)(a.cmb.out2_nchw - out_nchw) + 1);
-        a.cmb.out2_nchw = nullptr;
-      }
-    }
-    table = persist_table(rec.items, rec.count, stream);
-  }
-  if (table) {
-    unsigned* sync = (unsigned*)L.p(ws, L.off_psync);
-    ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, ((size_t)batch * kPersistDoneStride + kPersistGrid + 64) * 4, stream));
-    rc = launch_wino_persist(table, rec.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, kPersistGrid, stream);
-    if (rc == ODEHIP_OK) {
-      ++g_persist.launches;
-      return rc;
-    }
-    g_persist.enabled = 0;  // the launch was refused: fall through to one launch per layer, for good
-    (void)hipGetLastError();
-  }
-  for (int i = 0; i < rec.count; ++i) {  // replay the recorded layers as ordinary launches
-    ConvArgs a = rec.items[i];
-    if (a.dbg) a.cmb.out2_nchw = out_nchw + ((size_t)(uintptr_t)a.dbg - 1);
-    a.dbg = nullptr;
-    if ((rc = launch_conv(a, f->ks, stream)) != ODEHIP_OK) return rc;
-  }
-  return ODEHIP_OK;
+  const int rc2 = persist.finish(hbuf, hdev, out_nchw, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream);
+  return rc != ODEHIP_OK ? rc : rc2;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -465,12 +490,18 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
     return t;
   };
 
+  float hbuf[4096];
+  for (int i = 0; i + 1 < n_times; ++i) hbuf[i] = (float)(t_host[i + 1] - t_host[i]);  // as uploaded by the forward pass
   const int last_s = S - 1;
   const float wlast = method == ODEHIP_RK4 ? 0.125f : 1.0f;  // weight of the last stage's k in the step
   // seed: gradient w.r.t. the last stage's k of the last interval = wlast * h * grad_out[T-1]
   hipLaunchKernelGGL(scale_kernel, dim3(1024), dim3(256), 0, stream, L.gp(ws, n_times - 2, last_s, NH), L.go(ws, n_times - 1), 0.0f,
                      wlast, hdev + (n_times - 2), n4);
   const float* g = L.go(ws, n_times - 1);  // total gradient w.r.t. y[n+1]
+  // the reverse sweep is nothing but conv launches (all bookkeeping lives in their epilogues): one persistent launch
+  PersistScope persist;
+  if ((rc = persist.begin(f, f_dgrad, (n_times - 1) * S * NL)) != ODEHIP_OK) return rc;
+  auto sweep = [&]() -> int {
   for (int n = n_times - 2; n >= 0; --n) {
     float* gnext = gbuf[n & 1];
     // epilogue of the FIRST stage's chain: closes the interval and seeds the next one (which uses h[n-1])
@@ -534,6 +565,11 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
     }
     g = gnext;
   }
+  return ODEHIP_OK;
+  };
+  rc = sweep();
+  const int rc2 = persist.finish(hbuf, hdev, nullptr, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream);
+  if (rc != ODEHIP_OK || rc2 != ODEHIP_OK) return rc != ODEHIP_OK ? rc : rc2;
   rc = odehip_q4_to_nchw(g, grad_z0_nchw, batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
 

@@ -244,8 +244,9 @@ def test_persistent_trajectory_is_bit_identical_to_per_layer_launches(cuda, meth
 
 @pytest.mark.gpu
 def test_persistent_forward_with_saving_gives_identical_gradients(cuda):
-    """The saving forward of a training step takes the persistent launch too (only the hidden layers' destinations differ):
-    trajectory and every gradient must equal the per-layer-launch run bit for bit."""
+    """The saving forward of a training step and the reverse sweep (input-gradient chains with the ReLU-mask and reverse
+    Runge-Kutta epilogues) each run as one persistent launch: trajectory and every gradient must equal the per-layer-launch
+    run bit for bit."""
     import ode_rl_amd
     lib = ode_rl_amd._lib.load()
     torch.manual_seed(9)
@@ -269,7 +270,7 @@ def test_persistent_forward_with_saving_gives_identical_gradients(cuda):
         n0 = lib.odehip_persistent_trajectory_launches()
         got = run()
         if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
-            assert lib.odehip_persistent_trajectory_launches() == n0 + 1
+            assert lib.odehip_persistent_trajectory_launches() == n0 + 2  # the saving forward and the reverse sweep
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
     finally:
