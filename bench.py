@@ -118,6 +118,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("ODEHIP_BENCH_REHEARSAL"):   # N ranks on ONE GPU over gloo: exercises this file's N > 1 path on a 1-GPU box
             local = 0
+            # the persistent trajectory kernel holds every CU and assumes its process owns the GPU (one process per GPU): two of
+            # them sharing a card could each hold half the CUs waiting for the other half
+            os.environ["ODEHIP_PERSISTENT"] = "0"
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
