@@ -658,6 +658,10 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
   float scales[4096];
   ODEHIP_REQUIRE((n_times - 1) * S <= 4096, "odeint_adjoint_backward: too many evaluations");
   float* a_final = L.p(ws, L.off_xs);
+  // every interval is conv launches only (recomputed stages + input-gradient chains, all bookkeeping in their epilogues)
+  PersistScope persist;
+  if ((rc = persist.begin(f, f_dgrad, (n_times - 1) * S * NL * 2)) != ODEHIP_OK) return rc;
+  auto sweep = [&]() -> int {
   for (int n = n_times - 2; n >= 0; --n) {
     const float* y = L.y(ws, n + 1);                       // integrate from t[n+1] back to t[n]
     const float* a = L.gp(ws, n, 0, NH);                   // a_y at t[n+1]
@@ -744,6 +748,11 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
       if ((rc = chain(n, 3, w)) != ODEHIP_OK) return rc;
     }
   }
+  return ODEHIP_OK;
+  };
+  rc = sweep();
+  const int rc2 = persist.finish(hbuf, hdev, nullptr, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream);
+  if (rc != ODEHIP_OK || rc2 != ODEHIP_OK) return rc != ODEHIP_OK ? rc : rc2;
   rc = odehip_q4_to_nchw(a_final, grad_z0_nchw, batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
   return wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/true, scales, grad_w, grad_b, stream);

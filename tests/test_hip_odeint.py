@@ -275,3 +275,37 @@ def test_persistent_forward_with_saving_gives_identical_gradients(cuda):
             assert torch.equal(a, b)
     finally:
         lib.odehip_set_persistent_trajectory(was)
+
+
+@pytest.mark.gpu
+def test_persistent_fixed_grid_adjoint_gives_identical_gradients(cuda):
+    """odeint_adjoint on a fixed grid: the backward integration (recomputed stages + input-gradient chains) as one persistent
+    launch against one launch per layer -- bit for bit."""
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    torch.manual_seed(11)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
+    z0 = (torch.randn(6, 64, 16, 16, device=cuda) * 0.5).requires_grad_(True)
+    t = torch.arange(4, 8, dtype=torch.float64, device=cuda) / 8
+    go = torch.randn(4, 6, 64, 16, 16, device=cuda)
+
+    def run():
+        for p in f.parameters():
+            p.grad = None
+        z0.grad = None
+        out = ode_rl_amd.odeint_adjoint(f, z0, t, method="rk4")
+        (out * go).sum().backward()
+        return [out.detach().clone(), z0.grad.clone()] + [p.grad.clone() for p in f.parameters()]
+
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        ref = run()
+        lib.odehip_set_persistent_trajectory(1)
+        n0 = lib.odehip_persistent_trajectory_launches()
+        got = run()
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() == n0 + 2
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
