@@ -100,7 +100,7 @@ struct PersistState {
     ConvArgs* dev = nullptr;
     size_t cap = 0;
     unsigned long long stamp = 0;
-  } tab[4];
+  } tab[8];
   unsigned long long clock = 0;
   unsigned* host_err = nullptr;      // mapped, pinned: written by the kernel if a capped wait gives up
   unsigned* host_err_dev = nullptr;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(64, 1) void pingpong(unsigned* ctr, int a, int b, i
       if (sleep) __builtin_amdgcn_s_sleep(2);
       if (++guard > (1 << 22)) return;
     }
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (threadIdx.x == 0 && me == 0) *cycles = __builtin_amdgcn_s_memrealtime() - t0;
   if (threadIdx.x == 0) smem[0] = 1;
@@ -52,10 +52,13 @@ int main() {
   for (int sl = 0; sl < 2; ++sl)
     for (auto& p : pairs) {
       hipMemset(ctr, 0, 4);
-      void* args[] = {&ctr, (void*)&p[0], (void*)&p[1], nullptr, &cyc, &sl};
       int n = 1000;
-      args[3] = &n;
-      hipLaunchCooperativeKernel((const void*)pingpong, dim3(256), dim3(64), args, 160 * 1024, 0);
+      void* args[] = {&ctr};
+      (void)args;
+      hipMemset(cyc, 0, 8);
+      hipLaunchKernelGGL(pingpong, dim3(256), dim3(64), 160 * 1024, 0, ctr, p[0], p[1], n, cyc, sl);  // one workgroup per CU: all resident
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) printf("launch failed: %s\n", hipGetErrorString(e));
       unsigned long long c = 0;
       hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
       printf("ping-pong blocks %d <-> %d (xcd %u, %u), sleep=%d: %.1f ns per one-way hand-off\n", p[0], p[1], h[p[0]] & 15, h[p[1]] & 15, sl,
