@@ -50,6 +50,7 @@ struct PersistHook {
   bool fence;          // the sample's workgroups are NOT on one XCD: agent-scope release / acquire around the hand-off
   float* nchw_base;    // base of the NCHW result tensor (the table holds offsets into it, in `dbg`)
   unsigned long long* stamps;  // diagnostic (odehip_set_debug_buffer): 8 x 100 MHz timestamps of this layer, or null
+  int batch;
 };
 __device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
   if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
@@ -254,9 +255,14 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     e_combine = a.combine;
     e_relu = a.relu;
     e_dst = a.dst;
+    // a table whose step size only exists on the device (dopri5: h_by_value == 0) takes the shared epilogue for its
+    // stage-combine / reverse layers; ReLU-mask layers of such a table read *h_ptr here
+    if (e_combine == 1 && !a.h_by_value) e_combine = 3;
     if (e_combine == 2) {  // ReLU-mask backward layer: dst = scale * acc * (mask > 0); the mask values are fetched now
       const BwdArgs& w = a.bwd;
-      e_ks = w.sc_c + w.sc_h * a.cmb.atol;  // atol = the step size, resolved by the host
+      typedef const __attribute__((address_space(4))) float ConstF;
+      const float hb = a.h_by_value ? a.cmb.atol : (w.h_ptr ? *(ConstF*)w.h_ptr : 0.0f);  // constant during the launch
+      e_ks = w.sc_c + w.sc_h * hb;
       e_y = w.mask_src != nullptr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -399,6 +405,15 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     }
   }
   if (PERSIST) {
+    if (a.combine == 1 && a.cmb.err_partials) {
+      // adaptive error norm: this wave's partial goes to the slot the per-layer launch (grid (4, batch), XCD-remapped ids) would
+      // have used for workgroup (b, ct, rh), so the controller adds the same numbers in the same order
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+      const int nwg_pl = 4 * hk.batch, lid_pl = b * 4 + ct * 2 + rh;
+      const int bid_pl = (nwg_pl & 7) == 0 ? (lid_pl % (nwg_pl >> 3)) * 8 + lid_pl / (nwg_pl >> 3) : lid_pl;
+      if (lane == 0) a.cmb.err_partials[bid_pl * 4 + wave] = esum;
+    }
     // this wave's share of the layer is in L2 once its stores are acknowledged; then it counts itself in
     if (wave == 0) pstamp(hk, 6, lane);
     wait_vmcnt<0>();
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -470,6 +485,11 @@ __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs 
     fence |= (v != my_xcc);
   }
   fence = __builtin_amdgcn_readfirstlane(fence);
+  {  // an adaptive solver that finished while this launch was queued: nothing to do (uniform; constant during the launch)
+    typedef const __attribute__((address_space(4))) int ConstI;
+    const int* skip = pa.table[0].skip;
+    if (skip && *(ConstI*)skip) return;
+  }
   const int n_groups = nwg >> 2;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // A group walks TWO samples at a time, layer by layer in turn (when the batch gives it more than one): the hand-off latency of
@@ -500,7 +520,7 @@ __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs 
       for (int s = 0; s < n_interleaved; ++s) {
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence, pa.out_nchw,
-                                (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr};
+                                (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch};
         wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
       }
       src = src_next;

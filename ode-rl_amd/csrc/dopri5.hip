@@ -16,6 +16,7 @@
 #include <time.h>
 
 #include "odehip_internal.h"
+#include "persist.h"
 
 namespace odehip {
 
@@ -358,7 +359,8 @@ extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int b
   const size_t st = al256((size_t)batch * f->channels[0] * kPix * 4);
   const size_t hid = al256((size_t)batch * max_hidden(f) * kPix * 4);
   const size_t np = (size_t)batch * (f->channels[0] / 32) * 2 * 4;
-  return al256(sizeof(DopriState)) + al256((size_t)n_times * 8) + 3 * al256((np > 1024 ? np : 1024) * 4) + 2 * hid + 10 * st;
+  return al256(sizeof(DopriState)) + al256((size_t)n_times * 8) + 3 * al256((np > 1024 ? np : 1024) * 4) + 2 * hid + 10 * st +
+         al256(persist_sync_bytes(batch));
 }
 
 extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
@@ -405,6 +407,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   float* y1 = (float*)take(st_b);
   float* k[7];
   for (int i = 0; i < 7; ++i) k[i] = (float*)take(st_b);
+  unsigned* psync = (unsigned*)take(persist_sync_bytes(batch));
   const int* skip = &state->done;
 
   // exact-global mode: the kernels below read ONE already all-reduced scalar instead of the local partial arrays
@@ -507,6 +510,10 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   const double t_start = now_s();
   int enq = 0;
   for (;;) {
+    // the six evaluations of an attempt are conv launches only: one persistent launch (the same table for every attempt: the
+    // step size is read through h_ptr, the queued-behind-`done` case through the skip word)
+    PersistScope persist;
+    if ((rc = persist.begin(f, nullptr, 6 * f->n_convs)) != ODEHIP_OK) return rc;
     for (int s = 2; s <= 7; ++s) {  // k_s = f(x_s); fused: x_{s+1} = y + h*sum beta_{s+1,j} k_j   (s = 7: error norm)
       memset(&c, 0, sizeof(c));
       c.k_scale = ksc;
@@ -528,6 +535,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
       rc = enqueue_f(f, s < 7 ? xs : y1, batch, ping, pong, &c, nullptr, skip, stream);
       if (rc != ODEHIP_OK) return rc;
     }
+    if ((rc = persist.finish(nullptr, nullptr, nullptr, batch, psync, f->ks, stream)) != ODEHIP_OK) return rc;
     if (global_norm) {
       const float* arr[1] = {part0};
       const int lens[1] = {n_conv_partials};

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "odehip_internal.h"
+#include "persist.h"
 
 namespace odehip {
 
@@ -26,8 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static int n_stages(int method) { return method == ODEHIP_RK4 ? 4 : (method == ODEHIP_MIDPOINT ? 2 : 1); }
 constexpr int kEsplit = 4;
-constexpr int kPersistDoneStride = 64;  // words between per-sample counters (= kDoneStride in conv_wino.hip)
-constexpr int kPersistGrid = 256;  // the persistent trajectory kernel holds every CU of an MI355X (one workgroup each)
 
 // Everything lives in the caller's workspace; this is the one place that knows where.
 struct FixedLayout {
@@ -50,7 +49,7 @@ struct FixedLayout {
     off_k = take(3 * st);
     off_y = take((size_t)T * st);
     off_xin = off_hid = off_gp = off_go = off_gy = off_g2 = off_tab = off_slab = 0;
-    off_psync = take(((size_t)B * kPersistDoneStride + kPersistGrid + 64) * 4);  // persistent kernel: done[B] (a line each) + xcc_of[grid] + abort
+    off_psync = take(persist_sync_bytes(B));  // persistent kernel: flag line per sample + xcc_of[grid] + abort word
     if (save) {
       const size_t ne = (size_t)(T - 1) * S;
       off_xin = take(ne * st);             // stage inputs (slot s = 0 unused: it is y[n])
@@ -86,164 +85,6 @@ struct PtrPack {
 __global__ void fill_u64_kernel(unsigned long long* dst, PtrPack p, int n) {
   if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
 }
-
-// ---- persistent trajectory launch (conv_wino.hip: wino_persist_kernel) -----------------------------------------------------
-// The layer sequence of a call is recorded (launch_conv under g_conv_recorder) and handed over as a device table.  Tables are
-// kept in a small LIBRARY-OWNED device cache keyed by content (the one allocation this library makes on its own: a caller's
-// workspace may be reused by other entry points between calls, which would silently invalidate a table parked there); a
-// steady loop re-uses its table without any upload.  Result pointers are stored as offsets so that a fresh output tensor per
-// call does not change the table.
-struct PersistState {
-  std::mutex mu;
-  struct Entry {
-    std::vector<char> host;
-    ConvArgs* dev = nullptr;
-    size_t cap = 0;
-    unsigned long long stamp = 0;
-  } tab[8];
-  unsigned long long clock = 0;
-  unsigned* host_err = nullptr;      // mapped, pinned: written by the kernel if a capped wait gives up
-  unsigned* host_err_dev = nullptr;
-  int enabled = -1;                  // -1 unknown, 0 off (env, device, or a failed launch), 1 on
-  long long launches = 0;
-};
-static PersistState g_persist;
-
-static bool persist_available() {
-  PersistState& P = g_persist;
-  if (P.enabled >= 0) return P.enabled == 1;
-  P.enabled = 0;
-  const char* env = getenv("ODEHIP_PERSISTENT");
-  if (env && env[0] == '0') return false;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < kPersistGrid) return false;
-  if (hipHostMalloc((void**)&P.host_err, 64, hipHostMallocMapped) != hipSuccess) return false;
-  *P.host_err = 0;
-  if (hipHostGetDevicePointer((void**)&P.host_err_dev, P.host_err, 0) != hipSuccess) return false;
-  P.enabled = 1;
-  return true;
-}
-
-static bool persist_layer_ok(const ConvArgs& a) {
-  return a.qin == 16 && a.q1 == 16 && a.qout == 16 && a.w_wino && !a.w_bf16 && !a.src2 && !a.skip && a.combine >= 0 && a.combine <= 3 &&
-         !(a.combine == 1 && a.cmb.err_partials);
-}
-
-// device copy of `items` (identical content -> the cached copy); null on failure
-static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t stream) {
-  PersistState& P = g_persist;
-  const size_t bytes = (size_t)n * sizeof(ConvArgs);
-  PersistState::Entry* lru = &P.tab[0];
-  for (auto& e : P.tab) {
-    if (e.dev && e.host.size() == bytes && memcmp(e.host.data(), items, bytes) == 0) {
-      e.stamp = ++P.clock;
-      return e.dev;
-    }
-    if (e.stamp < lru->stamp) lru = &e;
-  }
-  if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;  // a running launch may still read the entry being replaced
-  if (lru->cap < bytes) {
-    if (lru->dev) (void)hipFree(lru->dev);
-    lru->dev = nullptr;
-    lru->cap = 0;
-    if (hipMalloc((void**)&lru->dev, bytes) != hipSuccess) return nullptr;
-    lru->cap = bytes;
-  }
-  lru->host.assign((const char*)items, (const char*)items + bytes);
-  if (hipMemcpy(lru->dev, items, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-    lru->host.clear();
-    return nullptr;
-  }
-  lru->stamp = ++P.clock;
-  return lru->dev;
-}
-
-// Records the conv launches of a driver between begin() and finish(); finish() runs them as one persistent launch, or replays
-// them one by one when the persistent path is unavailable.  Layers other than launch_conv calls must not be enqueued in between.
-class PersistScope {
- public:
-  PersistScope() : lock_(g_persist.mu, std::defer_lock) {}
-  ~PersistScope() { g_conv_recorder = nullptr; }
-  // rc != OK: a sticky error of an earlier launch was found.  active(): the recorder is on.
-  int begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers) {
-    if (f->ks != 3 || f->w_fused || (f2 && f2->w_fused) || g_debug_flags) return ODEHIP_OK;
-    for (int l = 0; l <= f->n_convs; ++l)
-      if (f->channels[l] != 64) return ODEHIP_OK;
-    for (int l = 0; l < f->n_convs; ++l)
-      if (!f->w_wino[l] || f->w_bf16[l] || (f2 && (!f2->w_wino[l] || f2->w_bf16[l]))) return ODEHIP_OK;
-    lock_.lock();
-    if (!persist_available()) {
-      lock_.unlock();
-      return ODEHIP_OK;
-    }
-    if (*g_persist.host_err) {
-      const unsigned code = *g_persist.host_err;
-      *g_persist.host_err = 0;
-      g_persist.enabled = 0;
-      set_error("an earlier persistent launch gave up waiting for a partner workgroup (code %u); its result is invalid.  "
-                "Persistent launches are now disabled for this process", code);
-      return ODEHIP_EINVAL;
-    }
-    items_.resize((size_t)max_layers);
-    rec_.items = items_.data();
-    rec_.count = 0;
-    rec_.capacity = max_layers;
-    g_conv_recorder = &rec_;
-    active_ = true;
-    return ODEHIP_OK;
-  }
-  bool active() const { return active_; }
-  // hbuf / hdev: host copy and device array of the step sizes (the table gets h by value); out_nchw may be null
-  int finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream) {
-    g_conv_recorder = nullptr;
-    if (!active_) return ODEHIP_OK;
-    active_ = false;
-    bool all_ok = rec_.count > 0;
-    for (int i = 0; i < rec_.count && all_ok; ++i) all_ok = persist_layer_ok(rec_.items[i]);
-    const ConvArgs* table = nullptr;
-    if (all_ok) {
-      for (int i = 0; i < rec_.count; ++i) {
-        ConvArgs& a = rec_.items[i];
-        a.dbg = nullptr;
-        // h by value, in a field no fixed-grid layer uses (read instead of *h_ptr)
-        const float* hp = a.combine == 1 ? a.cmb.h_ptr : (a.combine >= 2 ? a.bwd.h_ptr : nullptr);
-        a.cmb.atol = hp ? hbuf[hp - hdev] : (a.combine == 1 ? 1.0f : 0.0f);
-        if (a.combine == 1 && a.cmb.out2_nchw) {  // result frames as offsets: the output tensor is new every call
-          a.dbg = (unsigned long long*)(uintptr_t)((size_t)(a.cmb.out2_nchw - out_nchw) + 1);
-          a.cmb.out2_nchw = nullptr;
-        }
-      }
-      table = persist_table(rec_.items, rec_.count, stream);
-    }
-    int rc;
-    if (table) {
-      ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, ((size_t)batch * kPersistDoneStride + kPersistGrid + 64) * 4, stream));
-      rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
-                               kPersistGrid, stream);
-      if (rc == ODEHIP_OK) {
-        ++g_persist.launches;
-        return rc;
-      }
-      g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
-      (void)hipGetLastError();
-    }
-    for (int i = 0; i < rec_.count; ++i) {  // replay the recorded layers as ordinary launches
-      ConvArgs a = rec_.items[i];
-      if (a.dbg) a.cmb.out2_nchw = out_nchw + ((size_t)(uintptr_t)a.dbg - 1);
-      a.dbg = nullptr;
-      if (a.combine != 1) a.cmb.atol = 0.0f;
-      if ((rc = launch_conv(a, ks, stream)) != ODEHIP_OK) return rc;
-    }
-    return ODEHIP_OK;
-  }
-
- private:
-  std::unique_lock<std::mutex> lock_;
-  std::vector<ConvArgs> items_;
-  ConvRecorder rec_ = {nullptr, 0, 0};
-  bool active_ = false;
-};
 
 static int check_common(const odehip_convstack* f, int method, const double* t_host, int n_times, int batch, const char* who) {
   int rc = check_stack(f);
@@ -302,18 +143,6 @@ static int wgrad_all_layers(const odehip_convstack* f, const FixedLayout& L, voi
 }  // namespace odehip
 
 using namespace odehip;
-
-extern "C" int odehip_set_persistent_trajectory(int enable) {
-  std::lock_guard<std::mutex> g(g_persist.mu);
-  const int was = g_persist.enabled != 0;
-  g_persist.enabled = enable ? (g_persist.host_err ? 1 : -1) : 0;
-  return was;
-}
-
-extern "C" long long odehip_persistent_trajectory_launches(void) {
-  std::lock_guard<std::mutex> g(g_persist.mu);
-  return g_persist.launches;
-}
 
 extern "C" size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int method,
                                                 int save_for_backward) {

@@ -89,6 +89,7 @@ struct ConvArgs {
   int relu;
   int combine; // 0: plain store (+relu); 1: CombineArgs epilogue; 2/3: BwdArgs epilogues
   int debug;   // diagnostic ablation bits (tools/conv_microbench.py): 1 skip DMA, 2 skip MFMA, 4 skip epilogue
+  int h_by_value;  // persistent tables of fixed-grid drivers: cmb.atol holds the step size itself (read instead of *h_ptr)
   const int* skip;          // if non-null and *skip != 0 the kernel does nothing (adaptive solver already done)
   unsigned long long* dbg;  // debug & 8: per-workgroup stamps (8 x u64 per workgroup)
   CombineArgs cmb;

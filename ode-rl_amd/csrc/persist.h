@@ -1,0 +1,34 @@
+// persist.h -- host side of the persistent trajectory launch (conv_wino.hip: wino_persist_kernel), shared by the drivers.
+#pragma once
+#include <mutex>
+#include <vector>
+
+#include "odehip_internal.h"
+
+namespace odehip {
+
+constexpr int kPersistDoneStride = 64;  // words between per-sample flag lines (= kDoneStride in conv_wino.hip)
+constexpr int kPersistGrid = 256;       // the persistent kernel holds every CU of an MI355X (one workgroup each)
+inline size_t persist_sync_bytes(int batch) { return ((size_t)batch * kPersistDoneStride + kPersistGrid + 64) * 4; }
+
+// Records the conv launches of a driver between begin() and finish(); finish() runs them as one persistent launch, or replays
+// them one by one when the persistent path is unavailable.  Nothing but launch_conv calls may be enqueued in between.
+class PersistScope {
+ public:
+  PersistScope();
+  ~PersistScope();
+  // rc != OK: a sticky error of an earlier launch was found.  active(): the recorder is on.
+  int begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers);
+  bool active() const { return active_; }
+  // hbuf / hdev: host copy and device array of the step sizes (fixed grids: the table gets h by value), or null / null when the
+  // step size only exists on the device (dopri5); out_nchw may be null; sync: persist_sync_bytes(batch) of workspace
+  int finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream);
+
+ private:
+  std::unique_lock<std::mutex> lock_;
+  std::vector<ConvArgs> items_;
+  ConvRecorder rec_ = {nullptr, 0, 0};
+  bool active_ = false;
+};
+
+}  // namespace odehip

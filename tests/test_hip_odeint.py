@@ -309,3 +309,30 @@ def test_persistent_fixed_grid_adjoint_gives_identical_gradients(cuda):
             assert torch.equal(a, b)
     finally:
         lib.odehip_set_persistent_trajectory(was)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,rtol", [(64, 1e-4), (8, 1e-5)])
+def test_persistent_dopri5_attempts_are_bit_identical(cuda, batch, rtol):
+    """The six evaluations of a dopri5 attempt as one persistent launch: the error-norm partials land in the slots of the
+    per-layer launches, so the controller takes the same decisions and the trajectory is equal bit for bit."""
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    torch.manual_seed(13)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False).to(cuda)
+    z0 = torch.randn(batch, 64, 16, 16, device=cuda) * 0.5
+    t = torch.arange(10, 20, dtype=torch.float64, device=cuda) / 20
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        with torch.no_grad():
+            ref = ode_rl_amd.odeint(f, z0, t, rtol=rtol, atol=1e-5, method="dopri5")
+            ref_stats = dict(ode_rl_amd.last_stats)
+            lib.odehip_set_persistent_trajectory(1)
+            n0 = lib.odehip_persistent_trajectory_launches()
+            out = ode_rl_amd.odeint(f, z0, t, rtol=rtol, atol=1e-5, method="dopri5")
+            stats = dict(ode_rl_amd.last_stats)
+        assert torch.equal(out, ref) and stats == ref_stats
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() > n0
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
