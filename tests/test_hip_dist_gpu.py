@@ -35,7 +35,9 @@ def test_two_ranks_exact_global_dopri5_match_single_process(cuda, tmp_path):
     with socket.socket() as sk:   # a free rendezvous port on the loopback
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    # two ranks share ONE card here: the persistent launches (every CU, workgroups waiting for each other) assume one process per
+    # GPU, so the ranks use one launch per layer -- the results are bit-identical either way
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", ODEHIP_PERSISTENT="0")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_gpu_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(tmp_path / f"out{r}.pt"), str(tmp_path / "in.pt")],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
