@@ -53,8 +53,6 @@ int main() {
     for (auto& p : pairs) {
       hipMemset(ctr, 0, 4);
       int n = 1000;
-      void* args[] = {&ctr};
-      (void)args;
       hipMemset(cyc, 0, 8);
       hipLaunchKernelGGL(pingpong, dim3(256), dim3(64), 160 * 1024, 0, ctr, p[0], p[1], n, cyc, sl);  // one workgroup per CU: all resident
       hipError_t e = hipDeviceSynchronize();
