@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "odehip_internal.h"
+#include "persist.h"
 
 namespace odehip {
 
@@ -111,6 +112,11 @@ int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, fl
     }
     return launch_fstack_bf16(fa, batch, stream);
   }
+  // the layers of one evaluation as ONE persistent launch (64-channel fp32 stacks of at most 5 layers; inside a driver that
+  // records a longer sequence this scope stays inactive and the layers go to that recorder)
+  PersistScope one_eval;
+  int rcp = one_eval.begin(f, nullptr, f->n_convs, /*small=*/true);
+  if (rcp != ODEHIP_OK) return rcp;
   const float* cur = x_q4;
   for (int l = 0; l < f->n_convs; ++l) {
     const bool last = (l == f->n_convs - 1);
@@ -140,7 +146,7 @@ int enqueue_f_saving(const odehip_convstack* f, const float* x_q4, int batch, fl
     int rc = launch_conv(a, f->ks, stream);
     if (rc != ODEHIP_OK) return rc;
   }
-  return ODEHIP_OK;
+  return one_eval.finish(nullptr, nullptr, nullptr, batch, nullptr, f->ks, stream);
 }
 
 int enqueue_dgrad_chain(const odehip_convstack* f, const odehip_convstack* fd, int batch, float* const* gp,
@@ -162,6 +168,9 @@ int enqueue_dgrad_chain(const odehip_convstack* f, const odehip_convstack* fd, i
     fa.last.batch = batch;
     return launch_fstack_bf16(fa, batch, stream);
   }
+  PersistScope one_chain;  // as in enqueue_f_saving: the chain as one persistent launch
+  int rcp = one_chain.begin(f, fd, NL, /*small=*/true);
+  if (rcp != ODEHIP_OK) return rcp;
   for (int l = NL - 1; l >= 0; --l) {
     ConvArgs a;
     if (l > 0) {
@@ -185,7 +194,7 @@ int enqueue_dgrad_chain(const odehip_convstack* f, const odehip_convstack* fd, i
     int r = launch_conv(a, f->ks, stream);
     if (r != ODEHIP_OK) return r;
   }
-  return ODEHIP_OK;
+  return one_chain.finish(nullptr, nullptr, nullptr, batch, nullptr, f->ks, stream);
 }
 
 }  // namespace odehip

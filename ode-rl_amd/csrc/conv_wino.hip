@@ -18,6 +18,9 @@
 //              transform V = B^T d B of the next chunk (12 ds_read_b128 + 8 ds_write_b128 + float4 VALU per thread).
 // One s_barrier per chunk hands U_c / V_c to the consumers and the freed buffers back to the producers.
 // LDS: U[2] 64 KiB + raw[2] 32 KiB + V[2] 64 KiB = 160 KiB.
+#include <stddef.h>
+#include <string.h>
+
 #include "conv_common.h"
 
 namespace odehip {
@@ -43,7 +46,7 @@ __device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) {
 // read-modify-write anywhere).  A layer's input is complete once all 16 words have reached `target`.
 struct PersistHook {
   unsigned* done;
-  unsigned target;
+  unsigned target;     // epoch base + index of this layer (a launch that does not zero the flags tags them with its epoch)
   int word0;           // first of this workgroup's four words
   unsigned* abort_;    // device word: some wait of this launch has given up -- nobody waits any more
   unsigned* host_err;  // mapped host word: a capped wait gave up (never expected; the kernel then finishes with wrong data)
@@ -51,6 +54,8 @@ struct PersistHook {
   float* nchw_base;    // base of the NCHW result tensor (the table holds offsets into it, in `dbg`)
   unsigned long long* stamps;  // diagnostic (odehip_set_debug_buffer): 8 x 100 MHz timestamps of this layer, or null
   int batch;
+  unsigned abort_tag;  // value of *abort_ that means "this launch has given up" (epoch + 1)
+  bool first;          // layer 0 of the launch: its input was complete before the launch
 };
 __device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
   if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
@@ -71,9 +76,9 @@ __device__ __forceinline__ void wait_done(const PersistHook& hk) {
   while (!__all(lane >= 16 || __hip_atomic_load(hk.done + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
     __builtin_amdgcn_s_sleep(1);
     if ((++n & 1023) == 0) {
-      if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hk.abort_tag) break;
       if (n > (1 << 23)) {  // seconds: partners lost -- report and stop ALL waiting rather than hang the device
-        __hip_atomic_store(hk.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hk.abort_, hk.abort_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *hk.host_err = 3;
         break;
       }
@@ -190,7 +195,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     if (PERSIST) {
       if (pw == 0) pstamp(hk, 0, lane);
       issue_u(0, 0);                   // weights do not depend on the partners: requested before the wait
-      if (hk.target) wait_done(hk);    // the previous layer of this sample is complete in L2
+      if (!hk.first) wait_done(hk);    // the previous layer of this sample is complete in L2
       if (pw == 0) pstamp(hk, 1, lane);
       issue_raw(0, 0);
       issue_raw(1, 1);
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -461,33 +466,36 @@ struct PersistArgs {
   unsigned* host_err;
   float* out_nchw;        // base of the (T,B,C,16,16) result: table entries carry offsets into it (in `dbg`)
   unsigned long long* stamps;  // diagnostic: [64 layers][8] timestamps of logical workgroup 0, or null
+  unsigned epoch;         // 0: the flag area was zeroed for this launch; else the flags persist across launches and every word is
+                          // tagged with the epoch of the launch that wrote it (flag = epoch << 10 | layers done; xcc = epoch << 4 | id)
 };
 
-__global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs pa) {
+__device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvArgs* table) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nwg = gridDim.x;  // a multiple of 32: every XCD holds whole groups of 4
   const int lid = ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);
   const int rh = lid & 1, ct = (lid >> 1) & 1, group = lid >> 2;
   const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;  // HW_REG_XCC_ID[3:0]
-  if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned xtag = pa.epoch << 4;
+  if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, xtag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool fence = false;
   for (int p = 0; p < 4; ++p) {
     unsigned v = 0;
     int n = 0;
-    while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~3) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+    while (((v = __hip_atomic_load(pa.xcc_of + (lid & ~3) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~15u) != xtag || (v & 15u) == 0) {
       __builtin_amdgcn_s_sleep(2);
       if (++n > (1 << 23)) {
-        __hip_atomic_store(pa.xcc_of + nwg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pa.xcc_of + nwg, pa.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *pa.host_err = 2;
         break;
       }
     }
-    fence |= (v != my_xcc);
+    fence |= ((v & 15u) != my_xcc);
   }
   fence = __builtin_amdgcn_readfirstlane(fence);
   {  // an adaptive solver that finished while this launch was queued: nothing to do (uniform; constant during the launch)
     typedef const __attribute__((address_space(4))) int ConstI;
-    const int* skip = pa.table[0].skip;
+    const int* skip = table[0].skip;
     if (skip && *(ConstI*)skip) return;
   }
   const int n_groups = nwg >> 2;
@@ -499,34 +507,54 @@ __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs 
     // the table is read in place (uniform loads; a private copy would live in scratch) -- but a row that is first touched when
     // it is needed costs a trip to HBM on the critical path of every layer, so: the producers' two pointers are fetched a layer
     // ahead and the next row is pulled into L2 a layer ahead
-    const float* src = pa.table[0].src1;
-    const float* u = pa.table[0].w_wino;
+    const float* src = table[0].src1;
+    const float* u = table[0].w_wino;
     for (int l = 0; l < pa.n_layers; ++l) {
       // the table is constant for the whole launch: address space 4 lets the compiler fetch its fields with SCALAR loads (as a
       // plain global pointer they become vector loads, each followed by vmcnt(0), because the kernel also stores to global memory)
       typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
-      const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)pa.table + l);
+      const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
       const float* src_next = src;
       const float* u_next = u;
       if (l + 1 < pa.n_layers) {
-        src_next = pa.table[l + 1].src1;
-        u_next = pa.table[l + 1].w_wino;
+        src_next = table[l + 1].src1;
+        u_next = table[l + 1].w_wino;
         if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
-          const unsigned v = __builtin_nontemporal_load((const unsigned*)&pa.table[l + 1] + threadIdx.x * 16);
+          const unsigned v = __builtin_nontemporal_load((const unsigned*)&table[l + 1] + threadIdx.x * 16);
           asm volatile("" ::"v"(v));
         }
       }
 #pragma unroll 1
       for (int s = 0; s < n_interleaved; ++s) {
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
-        const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence, pa.out_nchw,
-                                (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch};
+        const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
+                                pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
+                                pa.epoch + 1u, l == 0};
         wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
       }
       src = src_next;
       u = u_next;
     }
   }
+}
+
+__global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs pa) { persist_walk(pa, pa.table); }
+
+// A short layer sequence (one evaluation of f, one input-gradient chain) with its table IN THE KERNEL ARGUMENTS: nothing to
+// upload or cache, so it also serves callers whose buffers change with every evaluation (adaptive solvers' backward passes, the
+// encoder loop).  The flag area is library-owned and never zeroed between launches: words carry the launch's epoch.
+constexpr int kSmallLayers = 5;
+struct SmallPersistArgs {
+  PersistArgs pa;
+  ConvArgs layers[kSmallLayers];
+};
+static_assert(sizeof(SmallPersistArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__global__ __launch_bounds__(512, 1) void wino_persist_small_kernel(const SmallPersistArgs sa) {
+  // the argument block itself is the table (constant address space: scalar loads, no private copy)
+  typedef const __attribute__((address_space(4))) char ConstC;
+  ConstC* base = (ConstC*)__builtin_amdgcn_kernarg_segment_ptr();
+  persist_walk(sa.pa, (const ConvArgs*)(const void*)(base + offsetof(SmallPersistArgs, layers)));
 }
 
 template <int NCHUNK>
@@ -566,9 +594,31 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
   pa.out_nchw = out_nchw;
   pa.stamps = g_debug_buf;
+  pa.epoch = 0;  // the caller zeroed the flag area
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
   hipLaunchKernelGGL(wino_persist_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned epoch,
+                              unsigned* host_err_dev, int grid, hipStream_t stream) {
+  static bool attr_set = false;
+  ODEHIP_REQUIRE(n_layers >= 1 && n_layers <= kSmallLayers && epoch >= 1, "wino_persist_small: bad arguments");
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int per_cu = 0;
+    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist_small_kernel, 512, kWinoLds));
+    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist_small: the kernel does not fit a CU");
+    attr_set = true;
+  }
+  SmallPersistArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.pa.table = nullptr; sa.pa.n_layers = n_layers; sa.pa.batch = batch; sa.pa.done = done; sa.pa.xcc_of = xcc_of;
+  sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.epoch = epoch;
+  for (int i = 0; i < n_layers; ++i) sa.layers[i] = items[i];
+  hipLaunchKernelGGL(wino_persist_small_kernel, dim3(grid), dim3(512), kWinoLds, stream, sa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

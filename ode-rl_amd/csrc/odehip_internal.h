@@ -104,6 +104,8 @@ struct ConvRecorder {
   int count, capacity;
 };
 extern thread_local ConvRecorder* g_conv_recorder;
+int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned epoch,
+                              unsigned* host_err_dev, int grid, hipStream_t stream);
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
                         float* out_nchw, int grid, hipStream_t stream);
 int launch_wino(const ConvArgs& a, hipStream_t stream);

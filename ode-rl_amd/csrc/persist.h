@@ -18,7 +18,9 @@ class PersistScope {
   PersistScope();
   ~PersistScope();
   // rc != OK: a sticky error of an earlier launch was found.  active(): the recorder is on.
-  int begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers);
+  // small: a sequence of at most 5 layers that is launched with its table in the kernel arguments (no cache, library-owned
+  // flags); such a scope stays inactive inside an outer scope, whose recorder then simply sees the layers
+  int begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers, bool small = false);
   bool active() const { return active_; }
   // hbuf / hdev: host copy and device array of the step sizes (fixed grids: the table gets h by value), or null / null when the
   // step size only exists on the device (dopri5); out_nchw may be null; sync: persist_sync_bytes(batch) of workspace
@@ -29,6 +31,7 @@ class PersistScope {
   std::vector<ConvArgs> items_;
   ConvRecorder rec_ = {nullptr, 0, 0};
   bool active_ = false;
+  bool small_ = false;
 };
 
 }  // namespace odehip

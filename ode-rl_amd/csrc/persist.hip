@@ -24,6 +24,10 @@ struct PersistState {
   unsigned* host_err_dev = nullptr;
   int enabled = -1;                  // -1 unknown, 0 off (env, device, or a failed launch), 1 on
   long long launches = 0;
+  // small launches: flag area that is never zeroed between launches (words are tagged with the launch's epoch)
+  unsigned* small_flags = nullptr;
+  int small_batch_cap = 0;
+  unsigned small_epoch = 0;
 };
 static PersistState g_persist;
 
@@ -77,9 +81,13 @@ static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t s
 }
 
 PersistScope::PersistScope() : lock_(g_persist.mu, std::defer_lock) {}
-PersistScope::~PersistScope() { g_conv_recorder = nullptr; }
+PersistScope::~PersistScope() {
+  if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;  // only the scope that installed the recorder removes it
+}
 
-int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers) {
+int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers, bool small) {
+    small_ = small;
+    if (small && (g_conv_recorder || max_layers > 5)) return ODEHIP_OK;  // inside an outer scope: its recorder takes the layers
     if (f->ks != 3 || f->w_fused || (f2 && f2->w_fused) || g_debug_flags) return ODEHIP_OK;
     for (int l = 0; l <= f->n_convs; ++l)
       if (f->channels[l] != 64) return ODEHIP_OK;
@@ -108,11 +116,44 @@ int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, i
   }
 
 int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream) {
-    g_conv_recorder = nullptr;
+    if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;
     if (!active_) return ODEHIP_OK;
     active_ = false;
     bool all_ok = rec_.count > 0;
     for (int i = 0; i < rec_.count && all_ok; ++i) all_ok = persist_layer_ok(rec_.items[i]);
+    if (small_ && all_ok && rec_.count <= 5) {
+      PersistState& P = g_persist;
+      bool ready = true;
+      if (batch > P.small_batch_cap || P.small_epoch >= (1u << 21)) {  // (re)allocate / re-zero the flag area: rare, synchronous
+        ready = hipStreamSynchronize(stream) == hipSuccess;
+        if (ready && batch > P.small_batch_cap) {
+          if (P.small_flags) (void)hipFree(P.small_flags);
+          P.small_flags = nullptr;
+          P.small_batch_cap = 0;
+          const int cap = batch < 64 ? 64 : batch;
+          ready = hipMalloc((void**)&P.small_flags, persist_sync_bytes(cap)) == hipSuccess;
+          if (ready) P.small_batch_cap = cap;
+        }
+        ready = ready && hipMemset(P.small_flags, 0, persist_sync_bytes(P.small_batch_cap)) == hipSuccess;
+        P.small_epoch = 0;
+      }
+      if (ready) {
+        for (int i = 0; i < rec_.count; ++i) {
+          rec_.items[i].dbg = nullptr;
+          rec_.items[i].h_by_value = 0;
+        }
+        const int rcs = launch_wino_persist_small(rec_.items, rec_.count, batch, P.small_flags,
+                                                  P.small_flags + (size_t)P.small_batch_cap * kPersistDoneStride, ++P.small_epoch,
+                                                  P.host_err_dev, kPersistGrid, stream);
+        if (rcs == ODEHIP_OK) {
+          ++P.launches;
+          return rcs;
+        }
+        P.enabled = 0;
+        (void)hipGetLastError();
+      }
+      all_ok = false;  // fall through to the replay
+    }
     const ConvArgs* table = nullptr;
     if (all_ok) {
       for (int i = 0; i < rec_.count; ++i) {
