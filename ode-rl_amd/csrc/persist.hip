@@ -88,6 +88,14 @@ PersistScope::~PersistScope() {
 int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers, bool small) {
     small_ = small;
     if (small && (g_conv_recorder || max_layers > 5)) return ODEHIP_OK;  // inside an outer scope: its recorder takes the layers
+    if (small) {
+      // Measured (dopri5 forward + backward, B=64): 55 us per 5-layer launch = 11 us per layer, no better than five launches --
+      // the last layer of an adaptive solver's evaluation combines up to six earlier stages through the shared epilogue
+      // (operands fetched AFTER the last MFMA, one dependent load after the other).  Off unless asked for, until that epilogue
+      // gets the prefetched-operand treatment of the fixed-grid one.
+      static const bool small_on = [] { const char* e = getenv("ODEHIP_PERSISTENT_SMALL"); return e && e[0] == '1'; }();
+      if (!small_on) return ODEHIP_OK;
+    }
     if (f->ks != 3 || f->w_fused || (f2 && f2->w_fused) || g_debug_flags) return ODEHIP_OK;
     for (int l = 0; l <= f->n_convs; ++l)
       if (f->channels[l] != 64) return ODEHIP_OK;
