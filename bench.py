@@ -5,6 +5,11 @@ One "step" = one `DiffEqSolver.forward(z0, t)` over one batch of synthetic Movin
 Inputs are resident in HBM before the timed region.  With --gpus N every rank integrates its own batch
 (weak scaling, no data-path collective: samples are independent under a fixed-grid solver).
 
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts its own N ranks: the parent spawns
+N child processes of this file (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment)
+BEFORE it makes any GPU call, waits for them and exits with the first non-zero exit code; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks already exist and nothing is spawned.
+
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- dominant kernel (wino_persist_kernel: the whole trajectory, Winograd F(2x2,3x3) on exact-fp32 MFMA, in one
                   launch; conv3x3_wino_kernel<4> per layer when the persistent path is off): algorithmic FLOP per launch /
@@ -60,6 +65,10 @@ def parse():
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-train-leg", action="store_true", help="skip the extra forward + backward (+ gradient all-reduce) leg of the record")
+    p.add_argument("--no-config0", action="store_true", help="skip the BASELINE configs[0] (B=4) GPU/CPU pair of the record")
+    p.add_argument("--launch-check", action="store_true",
+                   help="N ranks over gloo, no GPU work: exercises the self-launch and rendezvous path only (CPU tests)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     return p.parse_args()
 
@@ -68,10 +77,26 @@ def conv_flops(f_channels, batch):
     return sum(2 * batch * ci * co * 9 * 256 for ci, co in zip(f_channels[:-1], f_channels[1:]))
 
 
-def cpu_baseline(state, z0, t, method, budget_s):
+def host_cpu_info():
+    """`lscpu` model / sockets / cores of the box the CPU baseline ran on."""
+    import subprocess
+    info = {}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)"):
+                info[k] = v
+    except Exception as e:   # lscpu missing: say so rather than guess
+        info["error"] = repr(e)
+    return info
+
+
+def cpu_baseline(state, z0, t, method, budget_s, rtol=1e-4, atol=1e-5):
     """Time the oracle on the host cores: whole trajectories of the same workload until ~budget_s.
     torch-CPU convs on 16x16 maps scale badly past a few dozen threads, so a short sweep picks the
-    fastest intra-op thread count first (that count is what `cores` reports)."""
+    fastest intra-op thread count first (that count is what `cores` reports).  `value` uses the MEDIAN trajectory time."""
     from oracle import reference_modules as rm
     from oracle import torchdiffeq_ref
     ws, bs = rm.split_convnet_state(state, "gradient_net.")
@@ -79,43 +104,99 @@ def cpu_baseline(state, z0, t, method, budget_s):
     frames = z0.shape[0] * len(t)
     hw = torch.get_num_threads()
     best_n, best_t = hw, float("inf")
+    run = lambda: torchdiffeq_ref.odeint(f, z0, t, rtol=rtol, atol=atol, method=method)   # noqa: E731
     with torch.no_grad():
         for n in sorted({hw, 64, 32, 16, 8}, reverse=True):
             if n > hw:
                 continue
             torch.set_num_threads(n)
-            torchdiffeq_ref.odeint(f, z0, t, method=method)  # warm-up
+            run()  # warm-up
             t0 = time.perf_counter()
-            torchdiffeq_ref.odeint(f, z0, t, method=method)
+            run()
             el = time.perf_counter() - t0
             if el < best_t:
                 best_n, best_t = n, el
         torch.set_num_threads(best_n)
-        n, t0 = 0, time.perf_counter()
+        times, t_start = [], time.perf_counter()
         while True:
-            torchdiffeq_ref.odeint(f, z0, t, method=method)
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or n >= 400:
+            t0 = time.perf_counter()
+            run()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start >= budget_s or len(times) >= 400:
                 break
     torch.set_num_threads(hw)
-    return {"value": frames * n / el, "unit": "latent frames/s", "cores": best_n, "kind": "port",
-            "sample": f"{n} full trajectories of the same workload (B={z0.shape[0]}, T={len(t)}, {method}), "
-                      f"{el:.1f} s of torch-CPU fp32, no_grad, {best_n} intra-op threads (fastest of a sweep up to {hw})"}
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": frames / med, "unit": "latent frames/s", "cores": best_n, "kind": "port",
+            "host": host_cpu_info(), "torch_threads_available": hw,
+            "sample": f"{len(times)} full trajectories of the same workload (B={z0.shape[0]}, T={len(t)}, {method}), "
+                      f"{sum(times):.1f} s of torch-CPU fp32, no_grad, median trajectory time, {best_n} intra-op threads (fastest of a sweep up to {hw}); "
+                      "torchdiffeq is not installed: the oracle's restatement of torchdiffeq 0.2.1 is what is timed"}
+
+
+def self_launch(a):
+    """--gpus N without a launcher: one child process of this file per rank.  Runs BEFORE anything in this process touches
+    the GPU (torch.cuda.device_count() does not initialise it), and never replaces this process: children are spawned, waited
+    for, and their exit code is propagated.  Rank 0's stdout (the JSON line) is inherited."""
+    import socket
+    import subprocess
+    n = a.gpus
+    if not a.launch_check and not os.environ.get("ODEHIP_BENCH_REHEARSAL"):
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible (set ODEHIP_BENCH_REHEARSAL=1 to rehearse {n} ranks on one GPU over gloo)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # a failed rank would leave the others waiting at the rendezvous: stop exactly those PIDs
+                    q.terminate()
+    raise SystemExit(rc)
+
+
+def launch_check(rank, world):
+    """Rendezvous + one barrier + one MAX all-reduce over gloo; rank 0 prints a JSON line.  No GPU work."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    x = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "max_rank_seen": int(x.item())}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)     # does not return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if a.launch_check:
+        return launch_check(rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("ODEHIP_BENCH_REHEARSAL"):   # N ranks on ONE GPU over gloo: exercises this file's N > 1 path on a 1-GPU box
             local = 0
             # the persistent trajectory kernel holds every CU and assumes its process owns the GPU (one process per GPU): two of
@@ -197,82 +278,134 @@ def main():
         def step():
             graph.replay()
             return graph_out
-    for _ in range(a.warmup):
-        out = step()
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    persist0 = ode_rl_amd._lib.load().odehip_persistent_trajectory_launches()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(a.steps):
-        out = step()
-    ev1.record()
-    sync()
-    wall = time.perf_counter() - t0
-    assert out.shape == (T, a.batch, C0, 16, 16) and bool(torch.isfinite(out).all())
-    dev_ms = ev0.elapsed_time(ev1)
+    def measure(step_fn, steps, warmup):
+        """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; wall = MAX over ranks.
+        One HIP event between steps (on the stream the kernels are launched on: torch's current stream, which hip_ops hands to
+        the C ABI) gives the per-step device durations for the median without synchronising inside the region."""
+        for _ in range(warmup):
+            o = step_fn()
+        sync()
+        p0 = lib.odehip_persistent_trajectory_launches()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(steps):
+            o = step_fn()
+            evs[i + 1].record()
+        sync()
+        wall = time.perf_counter() - t0
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        wt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        return o, float(wt.item()), evs[0].elapsed_time(evs[steps]), per[len(per) // 2], lib.odehip_persistent_trajectory_launches() - p0
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall = float(wall_t.item())
+    lib = ode_rl_amd._lib.load()
+    out, wall, dev_ms, median_ms, persistent = measure(step, a.steps, a.warmup)
+    assert out.shape == (T, a.batch, C0, 16, 16) and bool(torch.isfinite(out).all())
+    fwd_stats = dict(ode_rl_amd.last_stats) if a.method == "dopri5" else {}
+    adj = dict(ode_rl_amd.last_adjoint_stats) if (a.method == "dopri5" and a.train and a.adjoint) else None
+
+    # ---- second leg of the record: the training step of the same workload (forward + backward through the solver + the ONE
+    # gradient all-reduce of north_star when N > 1), so the collective sits inside a timed region of every scaling run
+    train_leg = None
+    if not a.train and not a.no_train_leg and not a.graph:
+        gout2 = torch.randn(T, a.batch, C0, 16, 16, generator=torch.Generator().manual_seed(99)).to(dev)
+        from ode_rl_amd.dist import allreduce_gradients
+
+        def train_step():
+            zz = z0.detach().requires_grad_(True)
+            f.zero_grad(set_to_none=False)
+            o = solver(zz, t)
+            o.backward(gout2)
+            if dist is not None:
+                allreduce_gradients(f.parameters())
+            return o.detach()
+        ksteps = max(5, a.steps // 2)
+        _, twall, _, tmed, _ = measure(train_step, ksteps, 2)
+        train_leg = {"what": "forward + backward through the solver (discretise-then-optimise)" + (" + one flattened RCCL all-reduce of the gradients" if dist is not None else ""),
+                     "value": world * a.batch * T * ksteps / twall, "unit": "latent frames/s", "steps": ksteps,
+                     "ms_per_step": twall / ksteps * 1e3, "median_ms_per_step": tmed,
+                     "allreduce_bytes": 4 * sum(p.numel() for p in f.parameters()) if dist is not None else 0}
+
+    # ---- BASELINE configs[0] (the reference's own CPU-runnable case: B=4, same grid and method) on this GPU, next to its CPU time
+    config0 = None
+    if rank == 0 and world == 1 and not a.no_config0 and not a.train and a.batch != 4 and a.shape == "A" and not a.graph:
+        z4_cpu = torch.randn(4, C0, 16, 16, generator=torch.Generator().manual_seed(1234)) * 0.5
+        z4 = z4_cpu.to(dev)
+
+        def step4():
+            with torch.no_grad():
+                return solver(z4, t)
+        _, w4, _, m4, _ = measure(step4, 20, 5)
+        config0 = {"workload": f"BASELINE configs[0]: B=4, T={T}, {a.method}, {a.dtype}", "gpu": {"value": 4 * T * 20 / w4, "unit": "latent frames/s", "ms_per_step": w4 / 20 * 1e3, "median_ms_per_step": m4}}
+        if not a.no_cpu_baseline:
+            config0["cpu"] = cpu_baseline(state, z4_cpu, t_cpu, a.method, 3.0, rtol=solver.odeint_rtol, atol=solver.odeint_atol)
 
     if rank == 0:
         if a.method == "dopri5":
-            nfe_per_step = int(ode_rl_amd.last_stats.get("nfe", 0))
-            adj = dict(ode_rl_amd.last_adjoint_stats) if (a.train and a.adjoint) else None
+            nfe_per_step = int(fwd_stats.get("nfe", 0))
         else:
             nfe_per_step = {"rk4": 4, "midpoint": 2, "euler": 1}[a.method] * (T - 1)
         n_convs = len(chans) - 1
-        launches = nfe_per_step * n_convs * a.steps * (2 if a.train else 1)   # train: + the dgrad conv of every layer
-        if a.method == "dopri5" and a.train and a.adjoint:  # adaptive adjoint: each augmented evaluation = forward + dgrad convs
-            launches = (nfe_per_step + 2 * adj.get("nfe", 0)) * n_convs * a.steps
-        elif a.method == "dopri5" and a.train:  # forward + re-integration of the accepted steps + their dgrad chains
-            acc = int(ode_rl_amd.last_stats.get("n_accept", 0))
-            launches = (nfe_per_step + 2 * (6 * acc + 1)) * n_convs * a.steps
-        # ALGORITHMIC work of one 64->64 3x3 layer over the batch (direct-convolution FLOPs); the
-        # Winograd kernel executes 2.25x fewer MFMA FLOPs for it, so `frac` is algorithmic throughput over the MFMA peak
-        flop_per_launch = conv_flops(chans, a.batch) / n_convs      # average layer of f (A: every layer is 64 -> 64)
-        kernel = "conv3x3_wino_kernel<4>" if a.dtype == "f32" else "conv3x3_bf16_kernel<4>"
-        persistent = ode_rl_amd._lib.load().odehip_persistent_trajectory_launches() - persist0
-        if persistent == a.steps and not a.train:
+        F_f = conv_flops(chans, a.batch)                  # ALGORITHMIC FLOPs of one evaluation of f over the batch (SURVEY.md 8d)
+        fused_bf16 = a.dtype == "bf16" and a.shape == "A"    # 64 -> 64 stacks: fstack_bf16_kernel runs a whole f per launch
+        note = None
+        if a.train:
+            # a training step runs forward, input-gradient and weight-gradient kernels: no single kernel dominates, so the
+            # roofline entry is the whole step -- algorithmic work (forward F, dgrad F, wgrad F per evaluation) over its duration
+            if a.method == "dopri5" and a.adjoint:
+                evals = nfe_per_step + 3 * adj.get("nfe", 0)                      # augmented evaluation = forward + dgrad + wgrad
+            elif a.method == "dopri5":
+                evals = nfe_per_step + 3 * (6 * int(fwd_stats.get("n_accept", 0)) + 1)   # forward, then re-integration + reverse sweep
+            elif a.adjoint:
+                evals = nfe_per_step + 3 * nfe_per_step
+            else:
+                evals = 3 * nfe_per_step
+            kernel, launches, flop_per_launch = "whole training step (forward + input-gradient + weight-gradient kernels)", a.steps, F_f * evals
+            note = "launch = one training step; achieved = algorithmic FLOPs of all its conv work / step duration"
+        elif persistent == a.steps and a.dtype == "f32":
             # the whole trajectory is ONE launch of wino_persist_kernel: its algorithmic work = every layer of every f evaluation
             # (SURVEY.md section 8d: 339.7 MFLOP per latent frame for A, T=10); duration = the timed region / steps (the copy of
             # z0, the layout kernel and two tiny fills ride along: < 2 %)
-            kernel = "wino_persist_kernel"
-            flop_per_launch = conv_flops(chans, a.batch) * nfe_per_step
-            launches = a.steps
-        per_launch_s = dev_ms * 1e-3 / launches                      # HIP events, incl. inter-kernel gaps
+            kernel, launches, flop_per_launch = "wino_persist_kernel", a.steps, F_f * nfe_per_step
+        elif fused_bf16:
+            kernel, launches, flop_per_launch = "fstack_bf16_kernel", nfe_per_step * a.steps, F_f      # one launch per evaluation of f
+        else:
+            kernel = "conv3x3_wino_kernel<4>" if a.dtype == "f32" else "conv3x3_bf16_kernel"
+            launches, flop_per_launch = nfe_per_step * n_convs * a.steps, F_f / n_convs             # one launch per layer
+        per_launch_s = dev_ms * 1e-3 / launches                      # HIP events over the timed region, incl. inter-kernel gaps
         achieved = flop_per_launch / per_launch_s / 1e12
+        peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         res = {
             "metric": "integrated latent frames/sec (ODEConvGRU, MovingMNIST)",
             "value": world * a.batch * T * a.steps / wall,
             "unit": "latent frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": wall / a.steps * 1e3,
+            "ms_per_step": wall / a.steps * 1e3, "median_ms_per_step": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{'ODEConvGRU' if a.shape == 'A' else 'VidODE'} latents z0 (B={a.batch},{C0},16,16) per GPU, T={T} output frames "
                                    f"({T - 1} intervals), " + (f"adaptive dopri5 rtol {solver.odeint_rtol:g} atol {solver.odeint_atol:g}" if a.method == "dopri5"
-                                                                else f"fixed-step {a.method} (3/8 rule)") + ", f = " + ("5x conv3x3(64->64)+ReLU" if a.shape == "A" else "conv3x3 128->64->64->128 +ReLU (VidODE)") + ", "
+                                                                else f"fixed-step {a.method}" + (" (3/8 rule)" if a.method == "rk4" else "")) + ", f = " + ("5x conv3x3(64->64)+ReLU" if a.shape == "A" else "conv3x3 128->64->64->128 +ReLU (VidODE)") + ", "
                                    + (("forward + adjoint backward" + (f" ({a.adjoint_norm} norm)" if a.method == "dopri5" else "") if a.adjoint else
-                                       "forward + backward (discretise-then-optimise)") if a.train else "forward only (BASELINE configs[1])"),
+                                       "forward + backward (discretise-then-optimise)") if a.train else "forward only" + (" (BASELINE configs[1])" if (a.batch, T, a.method, a.dtype, a.shape) == (64, 10, "rk4", "f32", "A") else "")),
                        "per_gpu_batch": a.batch, "frames": T, "method": a.method, "parallelism": f"batch-shard x{world}" + (", exact-global dopri5 step control" if (a.method == "dopri5" and a.global_step_control and world > 1)
                                                                      else (", per-shard dopri5 step control" if (a.method == "dopri5" and world > 1) else "")),
                        "nfe": nfe_per_step, "adjoint_stats": adj if a.method == "dopri5" else None,
-                       "n_accept": int(ode_rl_amd.last_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
+                       "n_accept": int(fwd_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
             "roofline": {"bound": "mfma", "kernel": kernel,
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / (PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS),
-                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A") else None,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A" and kernel == "wino_persist_kernel") else None,
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
-                         "launches_timed": launches,
+                         "launches_timed": launches, "note": note,
                          # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the fp32 Winograd kernels execute 2.25x fewer
                          # on the matrix cores, so frac can exceed 1 -- the share of the MFMA peak actually executed is:
-                         "executed_mfma_frac": (achieved / 2.25 / PEAK_FP32_MFMA_TFLOPS) if a.dtype == "f32" else None},
+                         "executed_mfma_frac": (achieved / 2.25 / PEAK_FP32_MFMA_TFLOPS) if (a.dtype == "f32" and not a.train) else None},
+            "train": train_leg, "config0": config0,
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(state, z0_cpu, t_cpu, a.method, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(state, z0_cpu, t_cpu, a.method, a.cpu_seconds, rtol=solver.odeint_rtol, atol=solver.odeint_atol)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

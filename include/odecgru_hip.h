@@ -10,8 +10,22 @@
  * Conventions
  *   - every function returns 0 on success, a negative ODEHIP_E* code on failure;
  *     odehip_last_error() returns a static string for the calling thread.
- *   - enqueue-only: nothing synchronises the stream, nothing allocates device memory;
- *     scratch comes from caller-provided workspaces sized by the *_bytes() queries.
+ *   - scratch comes from caller-provided workspaces sized by the *_bytes() queries, and the compute entry points
+ *     are enqueue-only on the caller's stream, WITH THESE EXCEPTIONS (each is stated again at its entry point):
+ *       * the persistent-launch layer table: the library keeps up to 8 layer tables in device memory it owns; a call
+ *         whose table is not cached yet synchronises the stream once, may hipMalloc, and uploads with a blocking copy
+ *         (a steady loop re-uses its table: nothing is allocated, copied or synchronised);
+ *       * odehip_odeint_dopri5 returns after the device-side controller has reported completion: it polls a pinned
+ *         64 KiB host mailbox that the library allocates on first use (hipHostMalloc);
+ *       * odehip_odeint_adjoint_dopri5_backward reads one 8-byte verdict per attempted step from pinned host memory it
+ *         allocates on first use, and odehip_odeint_dopri5_backward synchronises once per layer for its wgrad table;
+ *       * the "small" persistent launches (ODEHIP_PERSISTENT_SMALL=1 only) own a flag area in device memory.
+ *   - library state (table cache, mailbox, error word, flag areas) is process-global and serves ONE stream at a time:
+ *     the library assumes one process per GPU driving it from a single stream (the Python binding passes torch's
+ *     current stream); concurrent calls from several streams or threads are not supported.
+ *   - a persistent launch whose in-kernel wait gives up (never observed; every wait is capped) sets a sticky error
+ *     word: the outputs of the call that was running are filled with NaN, odehip_persistent_error() reports the code,
+ *     and the next call that could use the persistent path fails with ODEHIP_EINVAL.
  *   - boundary tensors are fp32 NCHW, contiguous, H = W = 16 (the reference's latent map,
  *     models/ODEConvGRU.py:18-20 with resolution 64, n_downs 2).  Internally activations use
  *     the "Q4" layout [B][C/4][256 pixels][4 channels].
@@ -26,6 +40,7 @@
 extern "C" {
 #endif
 
+#define ODEHIP_ABI_VERSION 4 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -321,6 +336,10 @@ int odehip_adam_step(float* const* params, const float* const* grads, float* con
  * setting.  odehip_persistent_trajectory_launches: how many trajectories have taken that path in this process. */
 int odehip_set_persistent_trajectory(int enable);
 long long odehip_persistent_trajectory_launches(void);
+/* Sticky error word of the persistent launches: 0 = none, else the code a capped in-kernel wait left when it gave up (2: a
+ * partner workgroup never announced itself, 3: a partner's layer never arrived).  Host-side read of mapped memory, no
+ * synchronisation.  clear != 0 resets the word and switches the persistent path off for the process. */
+int odehip_persistent_error(int clear);
 
 /* Moving-MNIST-shaped frames rendered on the device (replaces the host generator dataloader.py:47-103 + the normalisation of
  * __getitem__ :217-218).  init: [batch][n_digits][4] doubles = x, y, v_x, v_y in the unit square (drawn by the host as

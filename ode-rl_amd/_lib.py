@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
+ABI_VERSION = 4   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
 MAX_LAYERS = 8
 MAX_STAGES = 7
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
@@ -102,6 +103,7 @@ SIGNATURES = {
                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_persistent_trajectory": (ctypes.c_int, [ctypes.c_int]),
     "odehip_persistent_trajectory_launches": (ctypes.c_longlong, []),
+    "odehip_persistent_error": (ctypes.c_int, [ctypes.c_int]),
     "odehip_mmnist_render": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
@@ -214,13 +216,21 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
+    got = lib.odehip_version()
+    if got != ABI_VERSION:   # the struct layouts above belong to exactly one ABI: an older / newer .so would read them wrongly
+        raise OdeHipError(f"{LIB_PATH} reports ABI version {got}, this binding needs {ABI_VERSION}: rebuild the library (make -C ode-rl_amd/csrc)")
     _lib = lib
     return lib
 
 
 def check(rc):
-    """Map the C status code to the exception the reference's Python path would raise."""
+    """Map the C status code to the exception the reference's Python path would raise.  Also looks at the sticky error word of
+    the persistent launches (a capped in-kernel wait that gave up): whatever launch set it has produced invalid results."""
     if rc == 0:
+        code = _lib.odehip_persistent_error(1) if _lib is not None else 0
+        if code:
+            raise OdeHipError(f"a persistent launch gave up waiting for a partner workgroup (code {code}): results of the call that "
+                              "was running are invalid (its outputs were filled with NaN); persistent launches are now disabled")
         return
     msg = load().odehip_last_error().decode("utf-8", "replace")
     if rc == -1:

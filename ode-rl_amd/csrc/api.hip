@@ -202,7 +202,7 @@ int enqueue_dgrad_chain(const odehip_convstack* f, const odehip_convstack* fd, i
 using namespace odehip;
 
 extern "C" const char* odehip_last_error(void) { return g_err; }
-extern "C" int odehip_version(void) { return 3; }
+extern "C" int odehip_version(void) { return ODEHIP_ABI_VERSION; }
 extern "C" void odehip_set_debug_flags(int flags) { g_debug_flags = flags; }
 extern "C" void odehip_set_debug_buffer(void* p) { g_debug_buf = (unsigned long long*)p; }
 

@@ -507,8 +507,8 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   // one attempt queued behind the running one keeps the GPU busy (enqueue ~0.1 ms < attempt ~0.4 ms).  Exact-global mode
   // enqueues a collective per attempt, so every rank must enqueue the same number of attempts: no run-ahead there.
   const int RUN_AHEAD = global_norm ? 0 : 1;
-  const double t_start = now_s();
-  int enq = 0;
+  double t_progress = now_s();
+  int enq = 0, seen = 0;
   for (;;) {
     // the six evaluations of an attempt are conv launches only: one persistent launch (the same table for every attempt: the
     // step size is read through h_ptr, the queued-behind-`done` case through the skip word)
@@ -548,7 +548,11 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
     ++enq;
     // bound the run-ahead; leave as soon as the controller reports done
     while (!g_mailbox->done && g_mailbox->steps_done + RUN_AHEAD < enq) {
-      if (now_s() - t_start > 120.0) {
+      if (g_mailbox->steps_done != seen) {   // the limit is on time WITHOUT progress, not on the whole integration
+        seen = g_mailbox->steps_done;
+        t_progress = now_s();
+      }
+      if (now_s() - t_progress > 120.0) {
         set_error("odeint_dopri5: no progress from the device for 120 s (steps done %d of %d enqueued)", g_mailbox->steps_done, enq);
         return ODEHIP_EHIP;
       }
@@ -557,10 +561,20 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   }
   // attempts enqueued after `done` do nothing (skip flag); wait for the last controller so the mailbox is final
   while (g_mailbox->steps_done < enq) {
-    if (now_s() - t_start > 120.0) {
+    if (g_mailbox->steps_done != seen) {
+      seen = g_mailbox->steps_done;
+      t_progress = now_s();
+    }
+    if (now_s() - t_progress > 120.0) {
       set_error("odeint_dopri5: device did not drain");
       return ODEHIP_EHIP;
     }
+  }
+  // the device has finished every attempt of this call: a persistent launch that gave up a wait is known NOW
+  if (const unsigned code = persist_error(true)) {
+    set_error("odeint_dopri5: a persistent launch gave up waiting for a partner workgroup (code %u); the trajectory is invalid.  "
+              "Persistent launches are now disabled for this process", code);
+    return ODEHIP_EHIP;
   }
   if (stats_host) {
     stats_host[0] = g_mailbox->nfe;

@@ -255,7 +255,12 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   return ODEHIP_OK;
   };
   rc = enqueue_steps();
-  const int rc2 = persist.finish(hbuf, hdev, out_nchw, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream);
+  int rc2 = persist.finish(hbuf, hdev, out_nchw, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream);
+  if (rc == ODEHIP_OK && rc2 == ODEHIP_OK) {
+    float* const regions[1] = {out_nchw};
+    const size_t floats[1] = {(size_t)n_times * st_f};
+    rc2 = persist.guard(regions, floats, 1, stream);
+  }
   return rc != ODEHIP_OK ? rc : rc2;
 }
 
@@ -264,6 +269,23 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
 //   f_dgrad: the stack of input-gradient convs, f_dgrad->w_packed[l] = pack(W_l, transpose_flip = 1), in the
 //            forward layer order; bias pointers unused.
 //   grad_out (T,B,C,16,16) NCHW -> grad_z0 (B,C,16,16) NCHW, grad_w[l] (OIHW), grad_b[l].
+// behind the last kernel of a backward pass whose sweep ran as a persistent launch: NaN-fill every gradient if that launch gave up
+static int guard_gradients(PersistScope& persist, const odehip_convstack* f, int batch, float* grad_z0, float* const* grad_w,
+                           float* const* grad_b, hipStream_t stream) {
+  float* regions[1 + 2 * ODEHIP_MAX_LAYERS];
+  size_t floats[1 + 2 * ODEHIP_MAX_LAYERS];
+  int n = 0;
+  regions[n] = grad_z0;
+  floats[n++] = (size_t)batch * f->channels[0] * kPix;
+  for (int l = 0; l < f->n_convs; ++l) {
+    regions[n] = grad_w ? grad_w[l] : nullptr;
+    floats[n++] = (size_t)f->channels[l + 1] * f->channels[l] * f->ks * f->ks;
+    regions[n] = grad_b ? grad_b[l] : nullptr;
+    floats[n++] = (size_t)f->channels[l + 1];
+  }
+  return persist.guard(regions, floats, n, stream);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method,
                                             const double* t_host, int n_times, int batch, const float* grad_out_nchw,
@@ -403,7 +425,9 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
   if (rc != ODEHIP_OK) return rc;
 
   // ---- weight / bias gradients: one launch per layer over all (T-1)*S evaluations
-  return wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/false, nullptr, grad_w, grad_b, stream);
+  rc = wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/false, nullptr, grad_w, grad_b, stream);
+  if (rc != ODEHIP_OK) return rc;
+  return guard_gradients(persist, f, batch, grad_z0_nchw, grad_w, grad_b, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -584,5 +608,7 @@ extern "C" int odehip_odeint_adjoint_backward(const odehip_convstack* f, const o
   if (rc != ODEHIP_OK || rc2 != ODEHIP_OK) return rc != ODEHIP_OK ? rc : rc2;
   rc = odehip_q4_to_nchw(a_final, grad_z0_nchw, batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
-  return wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/true, scales, grad_w, grad_b, stream);
+  rc = wgrad_all_layers(f, L, ws, n_times, batch, /*adjoint=*/true, scales, grad_w, grad_b, stream);
+  if (rc != ODEHIP_OK) return rc;
+  return guard_gradients(persist, f, batch, grad_z0_nchw, grad_w, grad_b, stream);
 }

@@ -25,6 +25,11 @@ class PersistScope {
   // hbuf / hdev: host copy and device array of the step sizes (fixed grids: the table gets h by value), or null / null when the
   // step size only exists on the device (dopri5); out_nchw may be null; sync: persist_sync_bytes(batch) of workspace
   int finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream);
+  // Enqueued behind a call's last kernel when finish() took the persistent path: if a capped wait of a persistent launch has
+  // given up (the mapped error word is set; never expected) the regions are filled with NaN, so the call that produced the
+  // invalid result cannot hand plausible-looking numbers to its caller.  No-op when nothing was launched persistently.
+  int guard(float* const* regions, const size_t* floats, int n, hipStream_t stream);
+  bool launched() const { return launched_; }
 
  private:
   std::unique_lock<std::mutex> lock_;
@@ -32,6 +37,10 @@ class PersistScope {
   ConvRecorder rec_ = {nullptr, 0, 0};
   bool active_ = false;
   bool small_ = false;
+  bool launched_ = false;
 };
+
+// host-side look at the sticky error word of the persistent launches (0 = none); clear != 0 resets it and disables the path
+unsigned persist_error(bool clear);
 
 }  // namespace odehip

@@ -80,7 +80,50 @@ static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t s
   return lru->dev;
 }
 
+constexpr int kGuardRegions = 24;
+struct GuardArgs {
+  const unsigned* host_err;
+  int n;
+  float* p[kGuardRegions];
+  unsigned long long floats[kGuardRegions];
+};
+
+__global__ void persist_guard_kernel(const GuardArgs a) {
+  if (__hip_atomic_load(a.host_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) return;
+  for (int r = 0; r < a.n; ++r)
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.floats[r]; i += (unsigned long long)gridDim.x * blockDim.x)
+      a.p[r][i] = __builtin_nanf("");
+}
+
+unsigned persist_error(bool clear) {
+  PersistState& P = g_persist;
+  if (!P.host_err) return 0;
+  const unsigned code = *P.host_err;
+  if (code && clear) {
+    *P.host_err = 0;
+    P.enabled = 0;
+  }
+  return code;
+}
+
 PersistScope::PersistScope() : lock_(g_persist.mu, std::defer_lock) {}
+
+int PersistScope::guard(float* const* regions, const size_t* floats, int n, hipStream_t stream) {
+  if (!launched_ || !g_persist.host_err_dev) return ODEHIP_OK;
+  for (int base = 0; base < n; base += kGuardRegions) {
+    GuardArgs a;
+    memset(&a, 0, sizeof(a));
+    a.host_err = g_persist.host_err_dev;
+    a.n = n - base < kGuardRegions ? n - base : kGuardRegions;
+    for (int i = 0; i < a.n; ++i) {
+      a.p[i] = regions[base + i];
+      a.floats[i] = regions[base + i] ? floats[base + i] : 0;
+    }
+    hipLaunchKernelGGL(persist_guard_kernel, dim3(64), dim3(256), 0, stream, a);
+    ODEHIP_CHECK_HIP(hipGetLastError());
+  }
+  return ODEHIP_OK;
+}
 PersistScope::~PersistScope() {
   if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;  // only the scope that installed the recorder removes it
 }
@@ -155,6 +198,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
                                                   P.host_err_dev, kPersistGrid, stream);
         if (rcs == ODEHIP_OK) {
           ++P.launches;
+          launched_ = true;
           return rcs;
         }
         P.enabled = 0;
@@ -187,6 +231,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
                                kPersistGrid, stream);
       if (rc == ODEHIP_OK) {
         ++g_persist.launches;
+        launched_ = true;
         return rc;
       }
       g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
@@ -212,6 +257,11 @@ extern "C" int odehip_set_persistent_trajectory(int enable) {
   const int was = g_persist.enabled != 0;
   g_persist.enabled = enable ? (g_persist.host_err ? 1 : -1) : 0;
   return was;
+}
+
+extern "C" int odehip_persistent_error(int clear) {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  return (int)persist_error(clear != 0);
 }
 
 extern "C" long long odehip_persistent_trajectory_launches(void) {

@@ -476,7 +476,9 @@ def odeint_dopri5_backward(stack, t, accepted, z0, grad_out):
     ns = len(accepted)
     lib = _lib.load()
     nbytes = lib.odehip_dopri5_backward_workspace_bytes(ctypes.byref(desc), b, n, ns)
-    ws = workspace(("dopri5_bwd", b, n, ns, tuple(desc.channels)), nbytes, grad_out.device)
+    # keyed WITHOUT the accepted-step count: that count drifts as the weights train, and a key per count would leave one
+    # multi-GB buffer behind for every count ever seen; workspace() replaces a buffer that has become too small
+    ws = workspace(("dopri5_bwd", b, n, tuple(desc.channels)), nbytes, grad_out.device)
     gz0 = torch.empty((b, c, 16, 16), dtype=torch.float32, device=grad_out.device)
     gws = [torch.empty_like(cv.weight) for cv in stack.convs]
     gbs = [torch.empty_like(cv.bias) for cv in stack.convs]

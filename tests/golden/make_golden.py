@@ -25,6 +25,10 @@ sys.dont_write_bytecode = True
 from oracle import torchdiffeq_ref  # noqa: E402
 
 
+VIG_SCALE = 2.5
+VIG_T = [0.0, 0.2, 0.4, 0.6, 0.8]
+
+
 def _install_stubs():
     sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.metrics")
     skm.structural_similarity = None
@@ -112,6 +116,30 @@ def main():
     out["memory.shape"] = np.array(mem.shape)
     out["memory.last"] = mem[:, -1].numpy()
     np.savez(os.path.join(HERE, "traj_A.npz"), **out)
+
+    # F5v: the same wiring on VIGOROUS dynamics.  On traj_A the state moves 2.4 % and euler / midpoint / rk4 agree to 1e-5,
+    # so a wrong tableau passes there.  Here the weights of F1 are scaled by VIG_SCALE and the grid is 4 steps of 0.2: the
+    # state moves ~140 % with half the ReLUs active, and euler / midpoint / classic RK4 / the 3/8 rule differ pairwise by
+    # >= 1e-3 (asserted in tests/test_oracle_golden.py), while a relative perturbation of z0 is not amplified (so fp32
+    # implementations still agree to ~1e-6).  Only outputs are stored: weights = f_A.npz * scale, z0 = traj_A.npz.
+    keep = [p_.detach().clone() for p_ in fA.parameters()]
+    with torch.no_grad():
+        for p_ in fA.parameters():
+            p_.mul_(VIG_SCALE)
+    tv = torch.tensor(VIG_T, dtype=torch.float64)
+    out = {"scale": np.float64(VIG_SCALE), "t": tv.numpy()}
+    for method in ("rk4", "euler", "midpoint", "dopri5"):
+        sol = DiffEqSolver(fA, method, device=dev)(z0, tv)
+        out[f"{method}.first"] = sol[1].numpy()
+        out[f"{method}.last"] = sol[-1].numpy()
+        out[f"{method}.norms"] = sol.flatten(1).norm(dim=1).numpy()
+    st = {}
+    torchdiffeq_ref.odeint(fA, z0, tv, rtol=1e-4, atol=1e-5, method="dopri5", stats=st)
+    out["dopri5.nfe"] = np.array([st["nfe"], st.get("n_accept", 0), st.get("n_reject", 0)])
+    np.savez(os.path.join(HERE, "traj_vig.npz"), **out)
+    with torch.no_grad():
+        for p_, k_ in zip(fA.parameters(), keep):
+            p_.copy_(k_)
 
     # F7: full ODEConvGRU.forward on a reduced config (32-channel latents), rk4
     torch.manual_seed(4)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(ode_rl_amd._lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.odehip_version() >= 1
+    assert lib.odehip_version() == ode_rl_amd._lib.ABI_VERSION
     assert lib.odehip_packed_weight_floats(64, 64, 3) == 64 * 64 * 9
 
 

@@ -6,7 +6,7 @@ and against the exact fp32 oracle to show the size of the bf16 error itself (<= 
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import record, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -158,3 +158,44 @@ def test_convgru_cell_and_encoder_bf16(cuda, bf16_mode):
     ref = dict(zip(names, rg[1:]))
     bad = {n: rel_l2(p.grad, ref[n]) for n, p in enc.named_parameters() if rel_l2(p.grad, ref[n]) > 1e-2}
     assert not bad, bad
+
+
+def test_config4_bf16_39_intervals(cuda, bf16_mode):
+    """BASELINE configs[4] as stated: bf16 compute, 20 -> 40 frames, i.e. T = 40 output points = 39 rk4 intervals (156 evaluations
+    of f whose bf16 rounding accumulates in the fp32 state), trajectory AND gradients, B=2, against the oracle emulating the
+    same arithmetic (bf16 operands, fp32 accumulate / state).  Tolerances as above: trajectory <= 1e-3, gradients <= 5e-3."""
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    f, _ = _f()
+    with torch.no_grad():   # kink-free dynamics (see test_hip_backward.py)
+        for i in (0, 2, 4, 6):
+            f.gradient_net[i].weight.mul_(0.15)
+            f.gradient_net[i].bias.copy_(torch.where(torch.arange(64) % 2 == 0, 2.5, -2.5))
+        f.gradient_net[8].weight.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+    ws = [w.requires_grad_(True) for w in ws]
+    bs = [b.requires_grad_(True) for b in bs]
+    g = torch.Generator().manual_seed(40)
+    z0 = (torch.randn(2, 64, 16, 16, generator=g) * 0.5).requires_grad_(True)
+    t = torch.arange(20, 60, dtype=torch.float64) / 60      # 20 observed + 40 predicted frames (SURVEY 8d, config 5)
+    gout = torch.randn(40, 2, 64, 16, 16, generator=g)
+    ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs, compute_dtype="bf16"), z0, t, method="rk4")
+    rg = torch.autograd.grad(ref, [z0] + ws + bs, gout)
+    with torch.no_grad():
+        exact = torchdiffeq_ref.odeint(rm.ode_func(ws, bs), z0, t, method="rk4")
+    f = f.to(cuda)
+    zd = z0.detach().to(cuda).requires_grad_(True)
+    sol = ode_rl_amd.odeint(f, zd, t, method="rk4")
+    assert sol.shape == (40, 2, 64, 16, 16)
+    z = z0.detach()
+    assert record("config4.traj.increment", rel_l2(sol.detach().cpu()[1:] - z, ref.detach()[1:] - z)) <= 1e-3
+    e = record("config4.traj.increment.vs_fp32", rel_l2(sol.detach().cpu()[1:] - z, exact[1:] - z))
+    assert 1e-4 <= e <= 2e-2, e     # really bf16, and of the expected size after 39 intervals
+    sol.backward(gout.to(cuda))
+    errs = [record("config4.grad_z0", rel_l2(zd.grad, rg[0]))]
+    convs = [m for m in f.gradient_net if isinstance(m, torch.nn.Conv2d)]
+    for i, (c, gw, gb) in enumerate(zip(convs, rg[1:6], rg[6:])):
+        errs += [record(f"config4.grad_w{i}", rel_l2(c.weight.grad, gw)), record(f"config4.grad_b{i}", rel_l2(c.bias.grad, gb))]
+    assert max(errs) <= 5e-3, errs

@@ -1,7 +1,11 @@
 """GPU parity of f(y) and of the fixed-grid trajectories against the oracle and the golden fixtures.
 
-Tolerances (fp32, stated per north_star): rel-L2 <= 1e-4 for trajectories (observed ~1e-6);
-f(y) alone <= 5e-6.
+Tolerances (fp32): f(y) alone <= 5e-6.  Trajectories: north_star asks for <= 1e-4 rel-L2, but on the gentle dynamics of
+traj_A.npz the methods themselves differ by less than that (euler vs rk4 7.6e-6, midpoint vs rk4 6.5e-8 on the last frame), so
+the tests assert (i) on traj_A the error of the INCREMENT sol - z0 (last frame <= 1.5e-6 against a smallest method gap of
+2.75e-6; first frame <= 4e-6 against 7.85e-6 -- one step moves the state by 0.27 %, so fp32 storage of y0 + dy alone costs ~1e-6), and
+(ii) <= 3e-6 against the vigorous-dynamics fixture traj_vig.npz, where the methods differ pairwise by >= 1e-3
+(tests/test_oracle_golden.py asserts that).  Observed values are recorded in profiles/r02_parity_observed.json.
 """
 import os
 
@@ -9,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_l2, state_dict_of
+from conftest import load_golden, record, rel_l2, state_dict_of, vigorous_case
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +51,13 @@ def test_f_V_matches_reference_fixture(cuda):
     assert rel_l2(out, torch.from_numpy(gold["out"])) <= 5e-6
 
 
+# error of the increment sol - z0 on traj_A.  Last frame: observed 5.6e-7, the closest pair of methods (midpoint, rk4) differs by
+# 2.75e-6.  First frame (ONE step: the increment is 0.27 % of z0, so fp32 storage of y0 + dy alone is ~1e-6 of it -- on the CPU
+# that made the fixture too): observed 1.6e-6, closest pair 7.85e-6.
+TRAJ_A_INCREMENT_TOL = 1.5e-6
+TRAJ_A_FIRST_STEP_TOL = 4e-6
+
+
 @pytest.mark.parametrize("method", ["rk4", "euler", "midpoint"])
 def test_fixed_grid_matches_golden_and_oracle(cuda, method):
     import ode_rl_amd
@@ -61,29 +72,131 @@ def test_fixed_grid_matches_golden_and_oracle(cuda, method):
         sol = solver(z0.to(cuda), t.to(cuda))
     assert sol.shape == (10, 2, 64, 16, 16)
     assert torch.equal(sol[0].cpu(), z0)  # solution[0] = y0 exactly
-    assert rel_l2(sol[1], torch.from_numpy(tr[f"{method}.first"])) <= 1e-4
-    assert rel_l2(sol[-1], torch.from_numpy(tr[f"{method}.last"])) <= 1e-4
-    np.testing.assert_allclose(sol.flatten(1).norm(dim=1).cpu().numpy(), tr[f"{method}.norms"], rtol=1e-4)
+    sol = sol.cpu()
+    # the state moves only 2.4 % here: compare the INCREMENT, or the unchanged z0 hides the solver's error
+    e_first = record(f"traj_A.{method}.first.increment", rel_l2(sol[1] - z0, torch.from_numpy(tr[f"{method}.first"]) - z0))
+    e_last = record(f"traj_A.{method}.last.increment", rel_l2(sol[-1] - z0, torch.from_numpy(tr[f"{method}.last"]) - z0))
+    assert e_first <= TRAJ_A_FIRST_STEP_TOL and e_last <= TRAJ_A_INCREMENT_TOL, (e_first, e_last)
+    for other in ("rk4", "euler", "midpoint"):   # ... and it is its OWN method's fixture that it matches
+        if other != method:
+            assert rel_l2(sol[-1] - z0, torch.from_numpy(tr[f"{other}.last"]) - z0) > TRAJ_A_INCREMENT_TOL
+    np.testing.assert_allclose(sol.flatten(1).norm(dim=1).numpy(), tr[f"{method}.norms"], rtol=2e-7)
     with torch.no_grad():
         ref = torchdiffeq_ref.odeint(_oracle_f(fa), z0, t, method=method)
-    assert rel_l2(sol, ref) <= 1e-4
+    assert record(f"traj_A.{method}.all.increment", rel_l2(sol[2:] - z0, ref[2:] - z0)) <= TRAJ_A_INCREMENT_TOL
+
+
+VIGOROUS_TOL = 3e-6   # HIP vs the reference-generated fixture on dynamics where the methods differ pairwise by >= 1e-3 (observed 1e-7 .. 3e-7)
+
+
+@pytest.mark.parametrize("method", ["rk4", "euler", "midpoint"])
+def test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture(cuda, method):
+    """tests/golden/traj_vig.npz (the reference's own DiffEqSolver on f_A's weights x 2.5, four steps of 0.2): the state moves
+    by 140 % of its norm and euler / midpoint / classic RK4 / 3/8 rule are >= 1e-3 apart, so <= 3e-6 here pins the method,
+    its tableau and the stage coefficients.  Persistent and per-layer launch paths both."""
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    sd, z0, t, vg = vigorous_case()
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    f.load_state_dict(sd)
+    f = f.to(cuda)
+    was = lib.odehip_set_persistent_trajectory(1)
+    try:
+        for persistent in (1, 0):
+            lib.odehip_set_persistent_trajectory(persistent)
+            with torch.no_grad():
+                sol = ode_rl_amd.DiffEqSolver(f, method, device=cuda)(z0.to(cuda), t.to(cuda)).cpu()
+            assert sol.shape == (5, 2, 64, 16, 16) and torch.equal(sol[0], z0)
+            e1 = record(f"traj_vig.{method}.first.p{persistent}", rel_l2(sol[1], torch.from_numpy(vg[f"{method}.first"])))
+            e4 = record(f"traj_vig.{method}.last.p{persistent}", rel_l2(sol[-1], torch.from_numpy(vg[f"{method}.last"])))
+            assert e1 <= VIGOROUS_TOL and e4 <= VIGOROUS_TOL, (e1, e4)
+            np.testing.assert_allclose(sol.flatten(1).norm(dim=1).numpy(), vg[f"{method}.norms"], rtol=VIGOROUS_TOL)
+            for other in ("rk4", "euler", "midpoint", "dopri5"):
+                if other != method:
+                    assert rel_l2(sol[-1], torch.from_numpy(vg[f"{other}.last"])) >= 2e-4, other
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
+
+
+def test_dopri5_on_vigorous_dynamics_matches_reference_fixture(cuda):
+    import ode_rl_amd
+    sd, z0, t, vg = vigorous_case()
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    f.load_state_dict(sd)
+    f = f.to(cuda)
+    with torch.no_grad():
+        sol = ode_rl_amd.DiffEqSolver(f, "dopri5", device=cuda)(z0.to(cuda), t.to(cuda)).cpu()
+    st = dict(ode_rl_amd.last_stats)
+    assert [st["nfe"], st["n_accept"], st["n_reject"]] == vg["dopri5.nfe"].tolist()
+    e1 = record("traj_vig.dopri5.first", rel_l2(sol[1], torch.from_numpy(vg["dopri5.first"])))
+    e4 = record("traj_vig.dopri5.last", rel_l2(sol[-1], torch.from_numpy(vg["dopri5.last"])))
+    assert e1 <= VIGOROUS_TOL and e4 <= VIGOROUS_TOL, (e1, e4)
+    assert rel_l2(sol[-1], torch.from_numpy(vg["rk4.last"])) >= 2e-4
+
+
+def test_memory_branch_matches_reference_fixture(cuda):
+    """DiffEqSolver(memory=True) (reference modules/DiffEqSolver.py:30-42): one odeint call per output point on a 1-element
+    t, which returns its input, so h_next = 2 * h_prev; BATCH-first result.  Fixture traj_A.npz: memory.* (reference run)."""
+    import ode_rl_amd
+    fa, tr = load_golden("f_A.npz"), load_golden("traj_A.npz")
+    f = _func_from_golden(fa, cuda, 64, 64, 3, 64)
+    z0, t = torch.from_numpy(tr["z0"]), torch.from_numpy(tr["t"])
+    for method in ("rk4", "dopri5"):
+        solver = ode_rl_amd.DiffEqSolver(f, method, device=cuda, memory=True)
+        with torch.no_grad():
+            mem = solver(z0.to(cuda), t[:3].to(cuda))
+        assert list(mem.shape) == tr["memory.shape"].tolist() == [2, 3, 64, 16, 16]    # (B, T, C, H, W)
+        assert torch.equal(mem[:, -1].cpu(), torch.from_numpy(tr["memory.last"]))      # doubling is exact in fp32
+        assert torch.equal(mem[:, 0].cpu(), 2 * z0)
 
 
 def test_rk4_uneven_grid_and_batch_odd(cuda):
-    """Ragged case: odd batch, non-uniform time grid, 2 time points, 1 time point."""
+    """Ragged case: odd batch, non-uniform time grid, 2 time points, 1 time point (vigorous dynamics, see above)."""
     import ode_rl_amd
+    from oracle import reference_modules as rm
     from oracle import torchdiffeq_ref
-    fa = load_golden("f_A.npz")
-    f = _func_from_golden(fa, cuda, 64, 64, 3, 64)
+    sd, _, _, _ = vigorous_case()
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    f.load_state_dict(sd)
+    f = f.to(cuda)
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
     g = torch.Generator().manual_seed(5)
     z0 = torch.randn(3, 64, 16, 16, generator=g) * 0.5
     for t in (torch.tensor([0.0, 0.07, 0.1, 0.35], dtype=torch.float64), torch.tensor([0.2, 0.9], dtype=torch.float64),
               torch.tensor([0.3], dtype=torch.float64)):
         with torch.no_grad():
             sol = ode_rl_amd.odeint(f, z0.to(cuda), t, method="rk4")
-            ref = torchdiffeq_ref.odeint(_oracle_f(fa), z0, t, method="rk4")
+            ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs), z0, t, method="rk4")
         assert sol.shape == ref.shape
-        assert rel_l2(sol, ref) <= 1e-4
+        assert record(f"uneven.rk4.T{len(t)}", rel_l2(sol, ref)) <= VIGOROUS_TOL
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_full_size_against_oracle(cuda, method):
+    """BASELINE configs[1] as stated (B=64, T=10, rk4, fp32, default-initialised weights, z0 = randn(seed 1234) * 0.5) and
+    configs[2]'s forward (dopri5, rtol 1e-5) compared DIRECTLY with the oracle on the same inputs, increment error."""
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    torch.manual_seed(0)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+    z0 = torch.randn(64, 64, 16, 16, generator=torch.Generator().manual_seed(1234)) * 0.5
+    t = torch.arange(10, 20, dtype=torch.float64) / 20
+    kw = dict(rtol=1e-5, atol=1e-5) if method == "dopri5" else {}
+    ost = {}
+    with torch.no_grad():
+        sol = ode_rl_amd.odeint(f.to(cuda), z0.to(cuda), t, method=method, **kw).cpu()
+        ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs), z0, t, method=method, stats=ost, **kw)
+    if method == "dopri5":
+        st = dict(ode_rl_amd.last_stats)
+        assert (st["nfe"], st["n_accept"], st["n_reject"]) == (ost["nfe"], ost.get("n_accept", 0), ost.get("n_reject", 0))
+    assert record(f"config1.{method}.B64.T10", rel_l2(sol, ref)) <= 1e-6
+    # dopri5's outputs come from torchdiffeq's quartic dense output, whose coefficients (e.g. 2dt(f1-f0) - 8(y1+y0) + 16 y_mid) cancel
+    # catastrophically in fp32: ~8 eps |y| absolute, i.e. ~2e-5 of an increment that is 2.4 % of |y| -- two correct fp32
+    # implementations differ at that level (observed 1.1e-5); the whole trajectory agrees to 1.6e-7
+    assert record(f"config1.{method}.B64.T10.increment", rel_l2(sol[1:] - z0, ref[1:] - z0)) <= (1.5e-6 if method == "rk4" else 5e-5)
 
 
 def test_full_size_properties(cuda):

@@ -5,7 +5,7 @@ the latent path: encoder cell -> z0 -> solver, against the oracle.  Tolerances a
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import record, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,9 @@ def test_solver_on_vidode_latents(cuda, method):
         ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs), z0, t, rtol=1e-4, atol=1e-5, method=method, stats=st)
         got = ode_rl_amd.DiffEqSolver(f.to(cuda), method, device=cuda)(z0.to(cuda), t.to(cuda))
     assert got.shape == (6, 3, 128, 16, 16)
-    assert rel_l2(got, ref) <= 1e-4
+    # increment error (the state moves little under default-initialised weights; z0 itself would hide the solver's error)
+    # (dopri5: fp32 cancellation in torchdiffeq's dense-output coefficients, see tests/test_hip_odeint.py; observed 1.1e-5, rk4 1e-6)
+    assert record(f"vidode.{method}.increment", rel_l2(got.cpu()[1:] - z0, ref[1:] - z0)) <= (3e-6 if method == "rk4" else 5e-5)
     if method == "dopri5":
         s = ode_rl_amd.last_stats
         assert (s["nfe"], s["n_accept"], s["n_reject"]) == (st["nfe"], st.get("n_accept", 0), st.get("n_reject", 0))

@@ -4,7 +4,7 @@ order differs only in the Euler update and the functional GroupNorm call)."""
 import numpy as np
 import torch
 
-from conftest import load_golden, rel_l2, state_dict_of
+from conftest import classic_rk4_step, load_golden, rel_l2, state_dict_of, vigorous_case
 from oracle import reference_modules as rm
 from oracle import torchdiffeq_ref as td
 
@@ -63,3 +63,34 @@ def test_solver_wiring_fixture():
     # memory=True branch (reference :30-42): odeint on a 1-element t returns its input => h_next = 2 h_prev, batch-first
     assert tr["memory.shape"].tolist() == [2, 3, 64, 16, 16]
     assert rel_l2(torch.from_numpy(tr["memory.last"]), 8 * z0) <= 1e-7
+
+
+def test_vigorous_fixture_discriminates_the_methods():
+    """F5v (tests/golden/traj_vig.npz, generated through the reference's own DiffEqSolver): the state moves by more than its own
+    norm, ReLUs are active, and euler / midpoint / classic RK4 / the 3/8 rule differ PAIRWISE by >= 1e-3 -- so the GPU test that
+    asserts <= 1e-5 against this fixture fails for a wrong tableau, a wrong stage coefficient or the wrong method."""
+    sd, z0, t, vg = vigorous_case()
+    ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+    f = rm.ode_func(ws, bs)
+    td._FIXED["_classic_rk4"] = classic_rk4_step
+    try:
+        with torch.no_grad():
+            sols = {m: td._integrate_fixed(f, z0, t, m, {}) for m in ("euler", "midpoint", "rk4", "_classic_rk4")}
+            st = {}
+            sols["dopri5"] = td.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5", stats=st)
+    finally:
+        del td._FIXED["_classic_rk4"]
+    for m in ("euler", "midpoint", "rk4", "dopri5"):   # the restatement reproduces the fixture
+        assert rel_l2(sols[m][-1], torch.from_numpy(vg[f"{m}.last"])) <= 1e-6
+        assert rel_l2(sols[m][1], torch.from_numpy(vg[f"{m}.first"])) <= 1e-6
+    assert [st["nfe"], st.get("n_accept", 0), st.get("n_reject", 0)] == vg["dopri5.nfe"].tolist()
+    move = float((sols["rk4"][-1] - z0).norm() / z0.norm())
+    assert move >= 1.0, move
+    hidden = torch.relu(torch.nn.functional.conv2d(sols["rk4"][-1], ws[0], bs[0], padding=1))
+    assert 0.3 <= float((hidden > 0).float().mean()) <= 0.7
+    names = ["euler", "midpoint", "rk4", "_classic_rk4"]
+    for i, a in enumerate(names):
+        for b in names[i + 1:]:
+            assert rel_l2(sols[a][-1], sols[b][-1]) >= 1e-3, (a, b)
+            assert rel_l2(sols[a][1], sols[b][1]) >= 1e-4, (a, b)   # already after ONE step
+    assert rel_l2(sols["dopri5"][-1], sols["rk4"][-1]) >= 2e-4
