@@ -215,11 +215,14 @@ typedef struct odehip_encoder {
 } odehip_encoder;
 
 size_t odehip_encoder_workspace_bytes(const odehip_encoder* e, int n_frames, int batch);
-/* inputs (T,B,C,16,16) time-first NCHW, t_host[T] float64 -> mean_z0, std_z0 (B,out_ch,16,16); latent (B,T,C,16,16) or NULL.
- * ODEConvGRUCell.forward / run_ode_conv_gru(run_backwards=True); `mask` is ignored as in the reference (ConvGRUCell.py:55-86). */
+/* inputs (T,B,C,16,16) time-first NCHW, t_host[T] float64 -> mean_z0, std_z0 (B,out_ch,16,16); latent (B,T,C,16,16) or NULL
+ * (slot k of a sample = the state after the k-th VISITED frame, as the reference stacks them, ODEConvGRUCell.py:74,76).
+ * ODEConvGRUCell.forward / run_ode_conv_gru: run_backwards != 0 visits the frames T-1 .. 0 (what forward() does, :33),
+ * 0 visits them 0 .. T-1 with the step sizes the reference's loop then produces (:47,73); `mask` is ignored as in the
+ * reference (ConvGRUCell.py:55-86). */
 int odehip_odeconvgru_encode(const odehip_encoder* e, const float* inputs_nchw, const double* t_host, int n_frames, int batch,
-                             float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             int run_backwards, float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* Backward of one ConvGRU step (ConvGRUCell.forward with seq_len = 1): grad_h_next -> grad_x, grad_h and the gradients of
  * the cell's eight parameters.  Stateless: the step is recomputed from (x, h) inside the call.  input_dim and hidden_dim
@@ -329,6 +332,27 @@ int odehip_conv_f43(const float* v, const float* u, const float* bias, float* ds
 int odehip_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                      const long long* numel, int n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, void* stream);
+
+/* ---- VidODE's warp chain + mask compositing (models/VidODE.py:119-140, get_warped_images :160-186) -------------------------- */
+
+/* pred_outputs (B,T,c+3,H,W) = the flow decoder's output per predicted frame: channels [0:2] optical flow (x, y) in pixels,
+ * [2:2+c] the "intermediate" frame, [2+c] the mask logit.  start_image (B,c,H,W) = the last observed frame.  grid_x[W], grid_y[H]
+ * = torch.linspace(-1, 1, n) (VidODE.py:122-123; handed over so that they are the caller's torch's values).  For t = 0..T-1:
+ *   warped_t = grid_sample(warped_{t-1}, grid + flow_t / ((n-1)/2), bilinear, padding_mode="border", align_corners=False)
+ *   masks_t = sigmoid(logit_t);  pred_x_t = masks_t * warped_t + (1 - masks_t) * intermediate_t
+ * with warped_{-1} = start_image -- the whole chain in ONE launch (one workgroup per sample, the image stays in LDS).
+ * Outputs: pred_x, warped (B,T,c,H,W), masks (B,T,1,H,W).  c <= 4, 2*c*H*W*4 bytes must fit in LDS (160 KiB). */
+int odehip_warp_composite(const float* pred_outputs, const float* start_image, const float* grid_x, const float* grid_y, int batch,
+                          int n_times, int channels, int height, int width, float* pred_x, float* warped, float* masks,
+                          void* stream);
+/* Backward of the above: gradients w.r.t. pred_outputs (flow through the bilinear weights -- zero where a coordinate was clamped
+ * to the border --, intermediate frames, mask logits) and, if grad_start_image != NULL, the start image.  `warped` is the forward's
+ * output; grad_warped / grad_masks may be NULL (no gradient arrives through those outputs).  The scatter into the previous
+ * image's gradient uses LDS float atomics: reproducible to rounding, not bitwise. */
+int odehip_warp_composite_backward(const float* pred_outputs, const float* start_image, const float* warped, const float* grid_x,
+                                   const float* grid_y, const float* grad_pred_x, const float* grad_warped, const float* grad_masks,
+                                   int batch, int n_times, int channels, int height, int width, float* grad_pred_outputs,
+                                   float* grad_start_image, void* stream);
 
 /* odehip_odeint_fixed runs a forward-only trajectory of a 64-channel fp32 stack as ONE persistent launch (the four workgroups of a
  * sample hand layers to each other through L2 instead of through launch boundaries).  On by default

@@ -104,6 +104,8 @@ SIGNATURES = {
     "odehip_set_persistent_trajectory": (ctypes.c_int, [ctypes.c_int]),
     "odehip_persistent_trajectory_launches": (ctypes.c_longlong, []),
     "odehip_persistent_error": (ctypes.c_int, [ctypes.c_int]),
+    "odehip_warp_composite": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 4),
+    "odehip_warp_composite_backward": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3),
     "odehip_mmnist_render": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p]),
@@ -167,7 +169,7 @@ SIGNATURES = {
                                                    ctypes.c_void_p]),
     "odehip_encoder_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(EncoderDesc), ctypes.c_int, ctypes.c_int]),
     "odehip_odeconvgru_encode": (ctypes.c_int, [ctypes.POINTER(EncoderDesc), ctypes.c_void_p,
-                                                ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_dopri5_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_int]),

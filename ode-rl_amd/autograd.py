@@ -127,6 +127,31 @@ def encode_with_grad(enc, inputs, timesteps):
     return _EncodeFn.apply(inputs, timesteps, enc, *hip_ops.encoder_params(enc))
 
 
+class _WarpCompositeFn(torch.autograd.Function):
+    """VidODE's warp chain + mask compositing (csrc/warp.hip): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, pred_outputs, start_image, grid_x, grid_y):
+        po, st = pred_outputs.detach().contiguous(), start_image.detach().contiguous()
+        gx, gy = grid_x.detach().contiguous(), grid_y.detach().contiguous()
+        pred_x, warped, masks = hip_ops.warp_composite(po, st, gx, gy)
+        ctx.save_for_backward(po, st, warped, gx, gy)
+        return pred_x, warped, masks
+
+    @staticmethod
+    def backward(ctx, g_pred_x, g_warped, g_masks):
+        po, st, warped, gx, gy = ctx.saved_tensors
+        g_po, g_start = hip_ops.warp_composite_backward(po, st, warped, gx, gy, g_pred_x, g_warped, g_masks, ctx.needs_input_grad[1])
+        return g_po, g_start, None, None
+
+
+def warp_composite(pred_outputs, start_image, grid_x, grid_y):
+    """(pred_x, warped_pred_x, pred_masks) of models/VidODE.py:119-138 from the flow decoder's output and the last observed frame."""
+    if torch.is_grad_enabled() and (pred_outputs.requires_grad or start_image.requires_grad):
+        return _WarpCompositeFn.apply(pred_outputs, start_image, grid_x, grid_y)
+    return hip_ops.warp_composite(pred_outputs, start_image, grid_x, grid_y)
+
+
 class _AdjointOdeint(torch.autograd.Function):
     """torchdiffeq.odeint_adjoint: forward without a graph, backward by integrating the adjoint ODE backwards."""
 

@@ -246,8 +246,8 @@ extern "C" size_t odehip_encoder_workspace_bytes(const odehip_encoder* e, int n_
 }
 
 extern "C" int odehip_odeconvgru_encode(const odehip_encoder* e, const float* inputs_nchw, const double* t_host, int n_frames,
-                                        int batch, float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace,
-                                        size_t workspace_bytes, void* stream_) {
+                                        int batch, int run_backwards, float* mean_nchw, float* std_nchw, float* latent_nchw,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
   ODEHIP_REQUIRE(e, "odeconvgru_encode: null descriptor");
   int rc = check_stack(&e->f_enc);
   if (rc != ODEHIP_OK) return rc;
@@ -280,11 +280,14 @@ extern "C" int odehip_odeconvgru_encode(const odehip_encoder* e, const float* in
   float* head_hid = take((size_t)batch * e->head_hidden * kPix * 4);
   float* head_out = take((size_t)batch * 2 * e->out_ch * kPix * 4);
 
-  // step sizes of the reverse-time Euler steps (ODEConvGRUCell.py:47,73): first -0.01, then t[i] - t[i+1]
+  // step sizes of the Euler steps (ODEConvGRUCell.py:47,73): first t[-1] - (t[-1] + 0.01); after visiting frame j the loop sets
+  // (prev_t, t_i) = (t[j], t[j-1]) -- Python indexing, so j = 0 wraps to t[-1] -- i.e. dt = t[j-1] - t[j].  Visiting order:
+  // T-1 .. 0 (run_backwards, the only order the reference's forward() uses, :33) or 0 .. T-1.
   FloatPack64 pk;
   for (int idx = 0; idx < n_frames; ++idx) {
-    const int i = n_frames - 1 - idx;  // frame visited at iteration idx
-    pk.v[idx] = idx == 0 ? (float)(t_host[n_frames - 1] - (t_host[n_frames - 1] + 0.01)) : (float)(t_host[i] - t_host[i + 1]);
+    const int j = run_backwards ? n_frames - idx : idx - 1;  // frame visited at iteration idx - 1
+    pk.v[idx] = idx == 0 ? (float)(t_host[n_frames - 1] - (t_host[n_frames - 1] + 0.01))
+                         : (float)(t_host[(j + n_frames - 1) % n_frames] - t_host[j]);
   }
   hipLaunchKernelGGL(fill64_kernel, dim3(1), dim3(64), 0, stream, dts, pk, n_frames);
   rc = odehip_nchw_to_q4(inputs_nchw, frames, n_frames * batch, C, stream);
@@ -293,7 +296,7 @@ extern "C" int odehip_odeconvgru_encode(const odehip_encoder* e, const float* in
 
   int cur = 0;
   for (int idx = 0; idx < n_frames; ++idx) {
-    const int i = n_frames - 1 - idx;
+    const int i = run_backwards ? n_frames - 1 - idx : idx;
     // h_ode = h + dt * f_enc(h)
     CombineArgs c;
     memset(&c, 0, sizeof(c));

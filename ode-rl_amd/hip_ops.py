@@ -761,7 +761,7 @@ def odeconvgru_encode_backward(enc, saved, grad_mean, grad_std):
     return gin, grads
 
 
-def odeconvgru_encode(enc, inputs, timesteps, want_latent=False):
+def odeconvgru_encode(enc, inputs, timesteps, want_latent=False, run_backwards=True):
     require_device_tensor(inputs, "inputs")
     d = enc.refresh()
     inputs = inputs.contiguous()
@@ -777,6 +777,41 @@ def odeconvgru_encode(enc, inputs, timesteps, want_latent=False):
     std = torch.empty_like(mean)
     latent = torch.empty((b, t, c, 16, 16), dtype=torch.float32, device=inputs.device) if want_latent else None
     tarr = (ctypes.c_double * t)(*t64)
-    _lib.check(lib.odehip_odeconvgru_encode(ctypes.byref(d), _ptr(inputs), tarr, t, b, _ptr(mean), _ptr(std), _ptr(latent),
-                                            _ptr(ws), ws.numel(), _stream()))
+    _lib.check(lib.odehip_odeconvgru_encode(ctypes.byref(d), _ptr(inputs), tarr, t, b, int(bool(run_backwards)), _ptr(mean), _ptr(std),
+                                            _ptr(latent), _ptr(ws), ws.numel(), _stream()))
     return mean, std, latent
+
+
+# ---- VidODE's warp chain + mask compositing (csrc/warp.hip) ---------------------------------------------------------------
+def warp_composite(pred_outputs, start_image, grid_x, grid_y):
+    """pred_outputs (B,T,c+3,H,W), start_image (B,c,H,W) -> pred_x, warped (B,T,c,H,W), masks (B,T,1,H,W); one launch."""
+    for t_, n_ in ((pred_outputs, "pred_outputs"), (start_image, "start_image"), (grid_x, "grid_x"), (grid_y, "grid_y")):
+        require_device_tensor(t_, n_)
+    pred_outputs, start_image = pred_outputs.contiguous(), start_image.contiguous()
+    b, t, cc, h, w = pred_outputs.shape
+    c = cc - 3
+    if tuple(start_image.shape) != (b, c, h, w) or grid_x.numel() != w or grid_y.numel() != h:
+        raise ValueError(f"warp_composite: start_image must be (B,{c},{h},{w}) and the grids ({w},), ({h},); got {tuple(start_image.shape)}")
+    pred_x = torch.empty((b, t, c, h, w), dtype=torch.float32, device=pred_outputs.device)
+    warped = torch.empty_like(pred_x)
+    masks = torch.empty((b, t, 1, h, w), dtype=torch.float32, device=pred_outputs.device)
+    _lib.check(_lib.load().odehip_warp_composite(_ptr(pred_outputs), _ptr(start_image), _ptr(grid_x.contiguous()), _ptr(grid_y.contiguous()),
+                                                 b, t, c, h, w, _ptr(pred_x), _ptr(warped), _ptr(masks), _stream()))
+    return pred_x, warped, masks
+
+
+def warp_composite_backward(pred_outputs, start_image, warped, grid_x, grid_y, g_pred_x, g_warped, g_masks, want_start_grad):
+    b, t, cc, h, w = pred_outputs.shape
+    c = cc - 3
+    g_pred_x = (torch.zeros_like(warped) if g_pred_x is None else g_pred_x).contiguous()
+    g_warped = g_warped.contiguous() if g_warped is not None else None
+    g_masks = g_masks.contiguous() if g_masks is not None else None
+    for t_ in (g_pred_x, g_warped, g_masks):
+        if t_ is not None:
+            require_device_tensor(t_, "gradient")
+    g_po = torch.empty_like(pred_outputs)
+    g_start = torch.empty_like(start_image) if want_start_grad else None
+    _lib.check(_lib.load().odehip_warp_composite_backward(_ptr(pred_outputs), _ptr(start_image), _ptr(warped), _ptr(grid_x), _ptr(grid_y),
+                                                          _ptr(g_pred_x), _ptr(g_warped), _ptr(g_masks), b, t, c, h, w, _ptr(g_po),
+                                                          _ptr(g_start), _stream()))
+    return g_po, g_start

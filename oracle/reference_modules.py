@@ -91,7 +91,7 @@ def convgru_cell(x, h, p, compute_dtype="f32"):
 
 
 # --------------------------------------------------------------------------- encoder loop
-def ode_convgru_encode(inputs, timesteps, f_enc, cell_params, head_params, compute_dtype="f32"):
+def ode_convgru_encode(inputs, timesteps, f_enc, cell_params, head_params, compute_dtype="f32", run_backwards=True):
     """`modules/ODEConvGRUCell.py:32-78`: reverse-time explicit-Euler + ConvGRU loop, then the
     1x1 -> ReLU -> 1x1 head, split into (mean_z0, |std_z0|).
 
@@ -102,7 +102,7 @@ def ode_convgru_encode(inputs, timesteps, f_enc, cell_params, head_params, compu
     prev = torch.zeros((B, C, H, W), dtype=inputs.dtype)
     prev_t, t_i = timesteps[-1] + 0.01, timesteps[-1]
     ys = []
-    for i in reversed(range(T)):
+    for i in (reversed(range(T)) if run_backwards else range(T)):   # :49-51
         inc = f_enc(prev_t, prev) * (t_i - prev_t)
         assert not torch.isnan(inc).any()
         ode_sol = prev + inc

@@ -22,7 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import torchdiffeq_ref  # noqa: E402
+from conftest import procedural_state_dict, procedural_tensor, vidode_state_dict  # noqa: E402
 
 
 VIG_SCALE = 2.5
@@ -37,6 +39,10 @@ def _install_stubs():
     td = types.ModuleType("torchdiffeq")
     td.odeint = torchdiffeq_ref.odeint
     sys.modules["torchdiffeq"] = td
+    # dataloader.py imports cv2 and torchvision.transforms at module level (used only by its "frozen" mp4 loader)
+    for name in ("cv2", "torchvision", "torchvision.transforms"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     sys.path.insert(0, "/root/reference")
 
 
@@ -44,8 +50,159 @@ def _np(sd, prefix=""):
     return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
+
+def gen_full_size(dev):
+    """F9 (full_size.npz): the reference's ConvGRUCell / ODEConvGRUCell / ODEConvGRU at the channel counts the path ships
+    (64 = ODEConvGRU, 128 = VidODE latents) with PROCEDURAL weights and inputs (tests/conftest.py: closed form of the indices),
+    so that only outputs need storing."""
+    import argparse as ap
+    from modules.DiffEqSolver import ODEFunc
+    from modules.ConvGRUCell import ConvGRUCell
+    from modules.ODEConvGRUCell import ODEConvGRUCell
+    from models.ODEConvGRU import ODEConvGRU
+    out = {}
+    for ch, b, T, seed in ((64, 2, 4, 11), (128, 1, 3, 12)):
+        cell = ConvGRUCell((16, 16), ch, ch, 5)
+        cell.load_state_dict(procedural_state_dict(cell.state_dict(), seed))
+        x, h = procedural_tensor((b, ch, 16, 16), seed + 100, -1, 1), procedural_tensor((b, ch, 16, 16), seed + 101, -1, 1)
+        _, h1 = cell(input_tensor=x[None], h_cur=h, seq_len=1)
+        out[f"cgru{ch}.out"] = h1.numpy()
+        f = ODEFunc(n_inputs=ch, n_outputs=ch, n_layers=3 if ch == 64 else 2, n_units=64, downsize=False, nonlinear="relu",
+                    final_act=False, device=dev)
+        enc = ODEConvGRUCell(f, None, (16, 16), ch, device=dev)
+        enc.load_state_dict(procedural_state_dict(enc.state_dict(), seed + 1))
+        inp = procedural_tensor((T, b, ch, 16, 16), seed + 102, -1, 1)
+        tt = torch.tensor(np.arange(T) / (2 * T))
+        mean, std = enc(inp, tt)
+        out[f"encode{ch}.mean"], out[f"encode{ch}.std"] = mean.numpy(), std.numpy()
+    cfg = dict(resolution=64, n_downs=2, conv_encoder_out_ch=64, in_channels=1, n_ode_layers=3, neural_ode_n_units=64,
+               neural_ode_decoder_out_ch=64, mem=False, z_sample=False)   # configs.yaml:593-605 (train_mmnist_odecgru_len20_1ch)
+    frames = procedural_tensor((2, 4, 1, 64, 64), 130, 0, 1)
+    ts = torch.tensor(np.arange(8) / 8)
+    for method in ("rk4", "dopri5"):
+        model = ODEConvGRU(ap.Namespace(decode_diff_method=method, **cfg), dev)
+        model.load_state_dict(procedural_state_dict(model.state_dict(), 13))
+        out[f"model64.{method}.pred"] = model(frames, {"observed_tp": ts[:4], "tp_to_predict": ts[4:]}).numpy()
+    np.savez_compressed(os.path.join(HERE, "full_size.npz"), **out)
+
+
+def gen_mmnist():
+    """F10 (mmnist.npz): the reference's on-the-fly generator (dataloader.py:47-103) and the normalisation of __getitem__
+    (:188-223) under a seeded Python `random`, on the build's procedural glyphs.  Stored: the frames the reference produced and
+    the draws (x, y, theta, glyph id) recovered by replaying `random` in the generator's order."""
+    import random
+    import dataloader as ref_dl
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_odehip_data", os.path.join(ROOT, "ode-rl_amd", "data.py"),
+                                                  submodule_search_locations=None)
+    src = open(os.path.join(ROOT, "ode-rl_amd", "data.py")).read()
+    ns = {}
+    exec(compile(src.split("def load_mnist")[0].replace("from . import _lib", ""), "data_glyphs", "exec"), ns)   # synthetic_digit_glyphs only
+    glyphs = ns["synthetic_digit_glyphs"]()
+    out = {"glyphs_crc": np.array([__import__("zlib").crc32(glyphs.tobytes())], dtype=np.int64)}
+    for case, (seed, n_in, n_out, num_objects) in enumerate(((5, 10, 10, [2]), (6, 20, 40, [3]), (7, 3, 2, [1]))):
+        ds = ref_dl.MovingMNIST.__new__(ref_dl.MovingMNIST)      # __init__ wants an MNIST file: set what it would have set
+        ds.frozen, ds.dataset, ds.device, ds.offset, ds.channels = False, None, torch.device("cpu"), 0, 1
+        ds.mnist, ds.is_train, ds.num_objects = glyphs, True, num_objects
+        ds.n_frames_input, ds.n_frames_output, ds.n_frames_total = n_in, n_out, n_in + n_out
+        ds.image_size_, ds.digit_size_, ds.step_length_ = 64, 28, 0.1
+        frames_in, frames_out, draws = [], [], []
+        for sample in range(2):
+            random.seed(1000 * seed + sample)
+            item = ds[sample]
+            frames_in.append(item["observed_data"].numpy())
+            frames_out.append(item["data_to_predict"].numpy())
+            random.seed(1000 * seed + sample)                    # replay the draws in the generator's order
+            nd = random.choice(num_objects)
+            d = []
+            for _ in range(nd):
+                x, y, th = random.random(), random.random(), random.random() * 2 * np.pi
+                d.append((x, y, th, random.randint(0, glyphs.shape[0] - 1)))
+            draws.append(d)
+        out[f"case{case}.observed"] = np.stack(frames_in)
+        out[f"case{case}.to_predict"] = np.stack(frames_out)
+        out[f"case{case}.draws"] = np.array(draws, dtype=np.float64)     # (sample, digit, [x, y, theta, id])
+    np.savez_compressed(os.path.join(HERE, "mmnist.npz"), **out)
+
+
+def _vidode_model(dev, method, seed):
+    import argparse as ap
+    from models.VidODE import VidODE
+    opt = ap.Namespace(n_downs=2, resolution=64, in_channels=1, n_layers=2, decode_diff_method=method)   # configs.yaml:710-721
+    model = VidODE(opt, dev)
+    model.load_state_dict(vidode_state_dict(model.state_dict(), seed))
+    return model
+
+
+def gen_vidode(dev):
+    """F11 (vidode.npz): the reference's own VidODE (models/VidODE.py), procedural weights and frames.
+    (a) `intended.*`: VidODE.forward with its two layout slips repaired AT THE MODULE BOUNDARY, nothing else touched: the
+        encoder cell is handed a time-first tensor (as models/ODEConvGRU.py:68 does; VidODE.py:105 passes batch-first and only
+        runs when B == T) and the solver's result is made batch-first before the `.view(b, T, ...)` of :110 (upstream permutes
+        inside its solver, Vid-ODE/models/ode_func.py:72).  train() mode (BatchNorm batch statistics) and eval() mode.
+    (b) `aswritten.*`: the unmodified forward on a B == T batch (the only shape it accepts), eval() mode."""
+    out = {}
+    B, Tin, Tout = 2, 3, 3
+    frames = procedural_tensor((B, Tin, 1, 64, 64), 140, 0, 1)
+    ts = torch.tensor(np.arange(Tin + Tout) / (Tin + Tout))
+    bd = {"observed_tp": ts[:Tin], "tp_to_predict": ts[Tin:], "observed_mask": torch.ones(B, Tin, 1),
+          "mask_predicted_data": torch.ones(B, Tout, 1)}
+    for mode in ("train", "eval"):
+        model = _vidode_model(dev, "rk4", 14)
+        getattr(model, mode)()
+        cell_fwd, solver_fwd = model.encoder_z0.forward, model.diffeq_solver.forward
+        caught = {}
+
+        def cell_time_first(x, tp, mask=None, _f=cell_fwd, _c=caught):
+            mu, std = _f(x.permute(1, 0, 2, 3, 4).contiguous(), tp, mask)
+            _c["mu"] = mu
+            return mu, std
+
+        def solver_batch_first(z, tp, _f=solver_fwd, _c=caught):
+            sol = _f(z, tp)
+            _c["sol"] = sol
+            return sol.permute(1, 0, 2, 3, 4)
+        model.encoder_z0.forward, model.diffeq_solver.forward = cell_time_first, solver_batch_first
+        flowmaps = model.get_flowmaps
+
+        def flowmaps_caught(sol_out, first_prev_embed, mask, _f=flowmaps, _c=caught):
+            _c["po"] = _f(sol_out=sol_out, first_prev_embed=first_prev_embed, mask=mask)
+            return _c["po"]
+        model.get_flowmaps = flowmaps_caught
+        pred, extra = model(frames, bd)
+        out[f"intended.{mode}.mask_logits"] = torch.cat(caught["po"], dim=1)[:, :, 2 + 1:].numpy()   # pre-sigmoid (forward keeps only the sigmoid)
+        out[f"intended.{mode}.pred_x"] = pred.numpy()
+        out[f"intended.{mode}.z0"] = caught["mu"].numpy()
+        out[f"intended.{mode}.sol_last"] = caught["sol"][-1].numpy()
+        for k in ("optical_flow", "warped_pred_x", "pred_intermediates", "pred_masks"):
+            out[f"intended.{mode}.{k}"] = extra[k].numpy()
+        if mode == "train":   # BatchNorm's running statistics after this one training-mode forward
+            sd = model.state_dict()
+            out["intended.train.bn_running_mean"] = sd["conv_encoder.cnn_encoder.1.running_mean"].numpy()
+            out["intended.train.bn_running_var_dec"] = sd["conv_decoder.cnn_decoder.2.running_var"].numpy()
+    n = 3
+    frames_sq = procedural_tensor((n, n, 1, 64, 64), 141, 0, 1)
+    bd = {"observed_tp": ts[:n], "tp_to_predict": ts[n:], "observed_mask": torch.ones(n, n, 1), "mask_predicted_data": torch.ones(n, n, 1)}
+    model = _vidode_model(dev, "rk4", 14).eval()
+    pred, extra = model(frames_sq, bd)
+    out["aswritten.eval.pred_x"] = pred.numpy()
+    out["aswritten.eval.optical_flow"] = extra["optical_flow"].numpy()
+    out["keys"] = np.array(sorted(model.state_dict().keys()))
+    out["n_params"] = np.array([sum(p.numel() for p in model.parameters())])
+    np.savez_compressed(os.path.join(HERE, "vidode.npz"), **out)
+
+
 def main():
     _install_stubs()
+    only = set(sys.argv[1:])   # e.g. `make_golden.py vidode mmnist full_size`; no argument = everything
+    if only:
+        dev = torch.device("cpu")
+        torch.set_grad_enabled(False)
+        for name in sorted(only):
+            fn = {"vidode": lambda: gen_vidode(dev), "mmnist": gen_mmnist, "full_size": lambda: gen_full_size(dev)}[name]
+            fn()
+        return
     from modules.DiffEqSolver import ODEFunc, DiffEqSolver  # reference
     from modules.ConvGRUCell import ConvGRUCell  # reference
     from modules.ODEConvGRUCell import ODEConvGRUCell  # reference
@@ -93,8 +250,9 @@ def main():
     tt = torch.tensor(np.arange(4) / 8)
     mean, std = enc(inp, tt)
     _, latent = enc.run_ode_conv_gru(inp, tt)
+    _, latent_fwd = enc.run_ode_conv_gru(inp, tt, run_backwards=False)   # frames visited 0 .. T-1 (never used by the reference's models)
     np.savez(os.path.join(HERE, "encode.npz"), inputs=inp.numpy(), t=tt.numpy(), mean=mean.numpy(),
-             std=std.numpy(), latent=latent.numpy(), **_np(enc.state_dict(), "sd."))
+             std=std.numpy(), latent=latent.numpy(), latent_fwd=latent_fwd.numpy(), **_np(enc.state_dict(), "sd."))
 
     # F5/F6: reference DiffEqSolver wiring (odeint := restatement), weights of F1
     z0 = torch.randn(2, 64, 16, 16, generator=torch.Generator().manual_seed(1234)) * 0.5
@@ -152,6 +310,10 @@ def main():
     pred = model(frames, {"observed_tp": ts[:4], "tp_to_predict": ts[4:]})
     np.savez(os.path.join(HERE, "model.npz"), frames=frames.numpy(), t=ts.numpy(), pred=pred.numpy(),
              keys=np.array(sorted(model.state_dict().keys())), **_np(model.state_dict(), "sd."))
+
+    gen_full_size(dev)
+    gen_mmnist()
+    gen_vidode(dev)
 
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

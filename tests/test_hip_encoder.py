@@ -61,6 +61,10 @@ def test_encoder_loop_matches_reference_fixture(cuda):
     assert torch.equal(last, latent[:, -1])
     with pytest.raises(AssertionError):
         enc(inp, t[:3])  # sequence length must match (reference :41)
+    # run_backwards=False (frames visited 0 .. T-1; never used by the reference's models, but part of the method's surface)
+    with torch.no_grad():
+        last_f, latent_f = enc.run_ode_conv_gru(inp, t, run_backwards=False)
+    assert rel_l2(latent_f, torch.from_numpy(g["latent_fwd"])) <= 5e-5 and torch.equal(last_f, latent_f[:, -1])
 
 
 def test_model_end_to_end_matches_reference_fixture(cuda):

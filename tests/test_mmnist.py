@@ -78,6 +78,23 @@ def test_device_frames_bit_exact(cuda, n_digits, t_in, t_out):
 
 
 @pytest.mark.gpu
+def test_device_frames_match_the_reference_generator(cuda):
+    """tests/golden/mmnist.npz = frames the REFERENCE's MovingMNIST produced under a seeded `random` (dataloader.py:47-103,
+    :188-223) on the build's glyphs, with the draws it consumed: the device renderer must reproduce them bit for bit."""
+    from conftest import load_golden
+    from ode_rl_amd import data
+    g = load_golden("mmnist.npz")
+    for case, (n_in, n_out) in enumerate(((10, 10), (20, 40), (3, 2))):
+        draws = g[f"case{case}.draws"]                      # (sample, digit, [x, y, theta, glyph id])
+        gen = data.MovingMNISTSynthetic(n_in, n_out, num_objects=[draws.shape[1]], batch_size=draws.shape[0], device=cuda)
+        st = {"x": draws[:, :, 0].copy(), "y": draws[:, :, 1].copy(), "theta": draws[:, :, 2].copy(), "ids": draws[:, :, 3].astype(np.int32)}
+        obs, pred = gen.render(st)
+        torch.cuda.synchronize()
+        assert np.array_equal(obs.cpu().numpy(), g[f"case{case}.observed"]), f"case {case}: observed frames differ"
+        assert np.array_equal(pred.cpu().numpy(), g[f"case{case}.to_predict"]), f"case {case}: frames to predict differ"
+
+
+@pytest.mark.gpu
 def test_device_frames_full_size_properties(cuda):
     from ode_rl_amd import data
     gen = data.MovingMNISTSynthetic(20, 40, num_objects=[2], batch_size=64, device=cuda, seed=7)

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Mutation check of the parity suite ("a deliberately wrong tableau coefficient turns the suite red").
+# Builds mutated copies of the library under gpurun_ab/mut/ (git-ignored scratch that travels to the GPU box) -- run with
+# `tools/mutation_check.sh build` HERE (hipcc cross-compiles), then `tools/mutation_check.sh run` on the GPU box: every mutant
+# must FAIL the forward parity tests, the unmutated library must pass them.  Summary -> gpurun_out/mutation_check.txt.
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+MUT=$ROOT/gpurun_ab/mut
+declare -A SED
+SED[rk4_stage3]='s/c.c1\[0\] = -third;/c.c1[0] = -0.25f;/'                                   # x3 = y + h (k2 - k1/3): -1/3 -> -1/4
+SED[rk4_weights_classic]='s/c.c2\[0\] = 0.125f;/c.c2[0] = 0.1666667f;/;s/c.c2\[3\] = 0.125f;/c.c2[3] = 0.1666667f;/;s/c.c2\[1\] = 0.375f;/c.c2[1] = 0.3333333f;/;s/c.c2\[2\] = 0.375f;/c.c2[2] = 0.3333333f;/'
+SED[midpoint_half]='s/c.c1\[0\] = 0.5f;/c.c1[0] = 0.45f;/'
+SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
+TESTS="tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle"
+case "${1:-}" in
+build)
+  for m in "${!SED[@]}"; do
+    d=$MUT/$m
+    rm -rf "$d"; mkdir -p "$d/ode-rl_amd/csrc" "$d/include"
+    cp "$ROOT"/ode-rl_amd/csrc/*.hip "$ROOT"/ode-rl_amd/csrc/*.h "$ROOT"/ode-rl_amd/csrc/Makefile "$d/ode-rl_amd/csrc/"
+    cp "$ROOT"/include/*.h "$d/include/"
+    sed -i "${SED[$m]}" "$d/ode-rl_amd/csrc/fixed_grid.hip" "$d/ode-rl_amd/csrc/odehip_internal.h"
+    if diff -q "$d/ode-rl_amd/csrc/fixed_grid.hip" "$ROOT/ode-rl_amd/csrc/fixed_grid.hip" >/dev/null && diff -q "$d/ode-rl_amd/csrc/odehip_internal.h" "$ROOT/ode-rl_amd/csrc/odehip_internal.h" >/dev/null; then
+      echo "mutant $m: the pattern matched nothing" >&2; exit 1
+    fi
+    make -s -C "$d/ode-rl_amd/csrc" -j8 OUT_DIR="$d/lib" >/dev/null 2>&1 || { echo "mutant $m failed to build" >&2; exit 1; }
+    rm -rf "$d/ode-rl_amd/csrc/build"
+    echo "built $m"
+  done ;;
+run)
+  out=$ROOT/gpurun_out/mutation_check.txt; : > "$out"
+  cd "$ROOT"
+  python -m pytest $TESTS -q > gpurun_out/mut_baseline.log 2>&1; rc=$?
+  echo "unmutated library: pytest rc=$rc ($(tail -1 gpurun_out/mut_baseline.log))" | tee -a "$out"
+  bad=0; [ $rc -ne 0 ] && bad=1
+  for d in "$MUT"/*/; do
+    m=$(basename "$d")
+    ODEHIP_LIB=$d/lib/libodecgru_hip.so python -m pytest $TESTS -q > gpurun_out/mut_$m.log 2>&1; rc=$?
+    echo "mutant $m: pytest rc=$rc ($(tail -1 gpurun_out/mut_$m.log)) failed: $(grep -c '^FAILED' gpurun_out/mut_$m.log)" | tee -a "$out"
+    grep '^FAILED' gpurun_out/mut_$m.log | sed 's/ - .*//' >> "$out"
+    [ $rc -eq 0 ] && { echo "  !! mutant $m SURVIVED" | tee -a "$out"; bad=1; }
+    # the mutant must fail on PARITY (an assertion of a test), not because it could not be loaded or crashed
+    if grep -qE "OdeHipError|AttributeError|OSError|Segmentation|core dumped" gpurun_out/mut_$m.log; then
+      echo "  !! mutant $m failed for the wrong reason (library not loaded / crash): rebuild the mutants" | tee -a "$out"; bad=1
+    fi
+  done
+  exit $bad ;;
+*) echo "usage: $0 build|run" >&2; exit 2 ;;
+esac
