@@ -143,19 +143,23 @@ size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int batch, int n
 /* z0: (B,C,16,16) NCHW; t_host: n_times float64 on the HOST, strictly increasing;
  * out: (n_times,B,C,16,16) NCHW, out[0] = z0.  One step per output interval.
  * negate != 0 integrates dz/dt = -f(z): torchdiffeq's handling of a strictly DEcreasing t is to flip the sign of t
- * and of the dynamics (_impl/odeint.py _check_inputs); the host passes -t here. */
+ * and of the dynamics (_impl/odeint.py _check_inputs); the host passes -t here.
+ * saved_format_out (required with save_for_backward, else may be NULL) receives how the workspace holds what the backward
+ * pass needs: 0 = one fp32 Q4 tensor per evaluation and layer (per-layer / per-evaluation launches), 1 = bf16 "Q4h" tensors
+ * written by the whole-trajectory bf16 launch (bf16 fused stack, rk4).  Hand it to odehip_odeint_fixed_backward. */
 int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
                         int n_times, int batch, float* out_nchw, int save_for_backward, int negate, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        size_t workspace_bytes, int* saved_format_out, void* stream);
 
 /* Backward of odehip_odeint_fixed(save_for_backward = 1), on the SAME workspace (untouched in between).
  * This is what `loss.backward()` (train_test.py:204) computes through torchdiffeq's fixed-grid ops: the exact gradient
  * of the discrete solver.  f_dgrad->w_packed[l] = odehip_pack_conv_weight(W_l, transpose_flip = 1) in forward layer
  * order (its bias pointers are ignored).  grad_out (T,B,C,16,16) -> grad_z0 (B,C,16,16), grad_w[l] (OIHW), grad_b[l].
- * Deterministic (no float atomics).  3x3 dynamics with channel counts that are multiples of 64. */
+ * Deterministic (no float atomics).  3x3 dynamics with channel counts that are multiples of 64.
+ * saved_format: what the forward call reported (0 or 1). */
 int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method, const double* t_host,
                                  int n_times, int batch, const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
-                                 float* const* grad_b, void* workspace, size_t workspace_bytes, void* stream);
+                                 float* const* grad_b, int saved_format, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Adjoint backward: torchdiffeq `odeint_adjoint` semantics (new capability; the reference uses plain autograd).  For
  * i = T-1..1 the augmented state (y, a_y, a_theta) is integrated from t[i] back to t[i-1] with one step of `method`,

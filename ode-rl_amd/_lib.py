@@ -143,11 +143,11 @@ SIGNATURES = {
     "odehip_odeint_fixed": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_int, ctypes.c_void_p,
                                            ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
-                                           ctypes.c_void_p]),
+                                           ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
     "odehip_odeint_fixed_backward": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.POINTER(ConvStack), ctypes.c_int,
                                                     ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
-                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t,
+                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                                     ctypes.c_void_p]),
     "odehip_odeint_adjoint_backward": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.POINTER(ConvStack), ctypes.c_int,
                                                       ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,

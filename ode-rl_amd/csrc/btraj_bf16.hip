@@ -1,0 +1,356 @@
+// btraj_bf16.hip -- the REVERSE sweep of a whole rk4 (3/8 rule) trajectory in ONE launch, bf16 compute (BASELINE.json configs[4],
+// forward + backward): the counterpart of ftraj_bf16_kernel<RK4, SAVE> (fstack_bf16.hip).  One workgroup per sample walks the
+// intervals T-2 .. 0 and, inside each, the stages 4 .. 1: every stage is the input-gradient chain of one evaluation of f (its five
+// transposed + flipped 3x3 convs on the matrix cores, the ReLU replaced by the mask of the activation the forward saved) followed
+// by the reverse Runge-Kutta bookkeeping -- which here happens in REGISTERS: the running gradient w.r.t. y and the gradients
+// w.r.t. k1, k2, k3 never leave the lane that owns their pixel and channels (the per-launch path keeps them in HBM and threads
+// them through the conv epilogues, fixed_grid.hip: odehip_odeint_fixed_backward; same expressions in the same order here).
+// What goes to HBM: the gradient w.r.t. every conv output, as bf16 "Q4h" (the weight-gradient kernel's operand; it is also what
+// the next conv of the chain multiplies), asynchronously; what comes from HBM: the saved masks (bf16, prefetched a layer ahead,
+// counted in the weight ring's vmcnt waits) and grad_out of the interval's left end.  The bias gradients are summed on the way
+// from the UNROUNDED fp32 gradients, in a fixed order (row sums by DPP, then LDS): deterministic.
+#include <string.h>
+
+#include "fused_bf16.h"
+
+namespace odehip {
+
+struct BtrajArgs {
+  const float* grad_out_nchw;            // (T,B,64,16,16)
+  float* grad_z0_nchw;                   // (B,64,16,16)
+  const float* hdev;                     // [T-1] step sizes
+  const void* w_fused;                   // dgrad image: layers in execution order NL-1 .. 0, transposed + flipped
+  const char* save_h;                    // forward's hidden activations: [e][l] Q4h
+  char* save_g;                          // out: gradient w.r.t. the output of conv l of evaluation e: [e][l] Q4h, l = 0 .. NL-1
+  float* bias_part;                      // out: [B][NL][64] per-sample bias-gradient sums (fp32)
+  unsigned long long stride_h_eval, stride_h_layer, stride_g_eval, stride_g_layer;
+  int n_layers, n_steps, batch;
+};
+
+typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x2b gload8_untracked(const char* p) {
+  u32x2b v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs ba) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const act = smem;
+  char* const ring = smem + kFTile;
+  float* const bsum = (float*)(smem + kFTile + kFStages * kFUnit);   // [NL][64] bias-gradient sums of this sample (the bias slot of the layout)
+  float* const bpart = bsum + ODEHIP_MAX_LAYERS * 64;                // [8 waves][4 rows of 16 lanes][16 channels]: row sums of one layer
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  const int NL = ba.n_layers, UE = NL * 3, S = 4;
+  const long long U = (long long)ba.n_steps * S * UE;
+
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(ba.w_fused, (unsigned)(UE * kFUnit));
+  const int vw = lane * 16;
+  auto issue = [&](int ue, int stage) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      dma16(rw, ring + stage * kFUnit + (wave * 3 + j) * 1024, vw, ue * kFUnit + (wave * 3 + j) * 1024);
+  };
+  issue(0, 0);
+  issue(1 % UE, 1);
+
+  for (int i = threadIdx.x; i < NL * 64; i += 512) bsum[i] = 0.0f;
+  for (int i = threadIdx.x; i < 68 * 9; i += 512) {  // zero border of the tile
+    const int p = i / 9, c16 = i % 9;
+    int row, col;
+    if (p < 18) { row = 0; col = p; }
+    else if (p < 36) { row = 17; col = p - 18; }
+    else if (p < 52) { row = p - 36 + 1; col = 0; }
+    else { row = p - 52 + 1; col = 17; }
+    *(f32x4*)(act + (row * 18 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int i32 = lane & 31, kq = lane >> 5;
+  const int px = i32 & 15, pyl = i32 >> 4;
+  const int mb = wave & 1, row0 = (wave >> 1) * 4 + pyl;
+  const int P0 = row0 * 16 + px, P1 = P0 + 32;
+  const char* const in = act + ((row0 + 1) * 18 + px + 1) * kFS + kq * 16;
+  const unsigned q4h_off = (unsigned)(((mb * 8 + kq) * kPix + P0) * 8);
+  const char* const save_h = wave_uniform(ba.save_h + (size_t)b * kQ4hSample);
+  char* const save_g = wave_uniform(ba.save_g + (size_t)b * kQ4hSample);
+
+  // v (fp32, accumulator layout) as bf16: into the tile (the next conv's operand) and into the saved gradient `dst` (8 stores)
+  auto emit = [&](const f32x16& v, int nb, char* dst) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int Q = mb * 8 + 2 * g + kq;
+      const u32x2 pk = {pk_bf16(v[4 * g], v[4 * g + 1]), pk_bf16(v[4 * g + 2], v[4 * g + 3])};
+      *(u32x2*)(act + ((row0 + 2 * nb + 1) * 18 + px + 1) * kFS + Q * 8) = pk;
+      *(u32x2*)(dst + (q4h_off + (unsigned)(g * 2 * kPix * 8 + nb * 32 * 8))) = pk;
+    }
+  };
+  // bias gradient of one conv output: sum over this wave's 64 pixels of the UNROUNDED gradient -- DPP sums inside the rows of 16
+  // lanes, the four row totals of each of the 16 channel registers parked in LDS; folded in a fixed order after the next barrier
+  auto bias_rows = [&](const f32x16& v0, const f32x16& v1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = v0[i] + v1[i];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));  // row_shr:1
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
+      if ((lane & 15) == 15) bpart[(wave * 4 + (lane >> 4)) * 16 + i] = v;   // lane 15 of a row holds the row's total
+    }
+  };
+  // channel ch (0..63) of conv-output gradient `layer`: waves with mb = ch / 32 hold it in register 4 g + j of lane half kq, where
+  // ch % 32 = 8 g + 4 kq + j; rows 2 kq, 2 kq + 1 of those waves' four rows belong to lane half kq
+  auto bias_fold = [&](int layer) {
+    if (threadIdx.x < 64) {
+      const int ch = threadIdx.x, m = ch >> 5, c = ch & 31, g = c >> 3, q = (c >> 2) & 1, j = c & 3;
+      float t = 0.0f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const float* p = bpart + ((2 * w4 + m) * 4 + 2 * q) * 16 + 4 * g + j;
+        t += p[0] + p[16];
+      }
+      bsum[layer * 64 + ch] += t;
+    }
+  };
+
+  // gradient state, accumulator layout: G = dL/dy_{n+1} (then the running dL/dy_n), gk[j] = dL/dk_{j+1}
+  f32x16 G[2], gk[3][2];
+  auto load_go = [&](int frame, f32x16 (&dst)[2]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* src = ba.grad_out_nchw + (((size_t)frame * ba.batch + b) * 64 + mb * 32 + 8 * g + 4 * kq) * kPix + (nb ? P1 : P0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[nb][4 * g + j] = src[(size_t)j * kPix];
+      }
+  };
+  load_go(ba.n_steps, G);
+  {  // seed of the last interval: (0 + wlast * h) * grad_out[T-1]   (fixed_grid.hip: scale_kernel)
+    const float c = 0.0f + 0.125f * ba.hdev[ba.n_steps - 1];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gk[0][nb][i] = G[nb][i] * c;
+  }
+
+  long long u = 0;
+  f32x16 acc0, acc1;
+  u32x2b mreg[8];
+  for (int n = ba.n_steps - 1; n >= 0; --n) {
+    const float h = ba.hdev[n];
+#pragma unroll
+    for (int s = 3; s >= 0; --s) {
+      const size_t ev = (size_t)n * S + s;
+      const char* const hs = wave_uniform(save_h + ev * ba.stride_h_eval);
+      char* const gs = wave_uniform(save_g + ev * ba.stride_g_eval);
+      // ---- seed of this stage's chain: dL/dk_s (fixed_grid.hip: the seeds / targets of the reverse sweep)
+      // (stage 4's seed gk4 = (h/8) g(y_{n+1}) was formed when g(y_{n+1}) was -- at the close of interval n+1, or before the
+      // loop -- and waits in gk[0], which is dead between an interval's close and its stage-4 bookkeeping)
+      constexpr int kSeedSlot[4] = {0, 1, 2, 0};
+      // the tile may still be read by a wave that lags in the previous chain's last row
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) emit(gk[kSeedSlot[s]][nb], nb, wave_uniform(gs + (size_t)(NL - 1) * ba.stride_g_layer));
+      bias_rows(gk[kSeedSlot[s]][0], gk[kSeedSlot[s]][1]);
+      for (int e = 0; e < NL; ++e) {       // executed layer e = conv NL-1-e backwards
+        const int l = NL - 1 - e;
+        const bool has_mask = e < NL - 1;
+        if (has_mask) {                      // mask of the ReLU that fed conv l = saved hidden activation l-1, prefetched now
+          const char* mk = wave_uniform(hs + (size_t)(l - 1) * ba.stride_h_layer);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mreg[i] = gload8_untracked(mk + (q4h_off + (unsigned)((i & 3) * 2 * kPix * 8 + (i >> 2) * 32 * 8)));
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r, ++u) {
+          // unit u landed?  younger than its DMAs: the next unit's 3 DMAs and, for the first two units of a layer, the 8 stores of
+          // the previous layer's gradient (or of the seed) and this layer's 8 mask loads
+          if (u == 0 || u + 1 >= U) wait_le<0>();
+          else if (r < 2 && e == NL - 1) wait_le<3 + 8>();
+          else if (r < 2) wait_le<3 + 16>();
+          else wait_le<3>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (u + 2 < U) issue((int)((u + 2) % UE), (r + 2) % 3);
+          if (r == 0) {
+            bias_fold(l);                    // the row sums parked before this barrier belong to the gradient w.r.t. conv l's output
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+          }
+          // same order of the 36 MFMAs per accumulator as fstack_bf16_kernel (tap, then channel block): the fp32 sums -- hence the
+          // bf16 roundings of the gradients -- are then identical to the per-evaluation path's
+          u32x4 xc[2][4];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) xc[nb][cb] = *(const u32x4*)(in + ((r - 1) * 18 + nb * 36) * kFS + cb * 32);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const char* wb = ring + r * kFUnit + c * 8192 + mb * 1024 + vw;
+            bf16x8 w[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) w[cb] = *(const bf16x8*)(wb + cb * 2048);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) {
+                u32x4 xs = xc[nb][cb];
+                if (c == 0) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) xs[j] = __builtin_amdgcn_update_dpp(0u, xc[nb][cb][j], 0x111, 0xf, 0xf, true);
+                } else if (c == 2) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) xs[j] = __builtin_amdgcn_update_dpp(0u, xc[nb][cb][j], 0x101, 0xf, 0xf, true);
+                }
+                const bf16x8 xv = __builtin_bit_cast(bf16x8, xs);
+                if (nb == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb], xv, acc0, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb], xv, acc1, 0, 0, 0);
+              }
+            }
+          }
+        }
+        if (!has_mask) break;
+        // hidden layer of the chain: gradient w.r.t. conv l-1's output = acc masked by (saved activation > 0); store + tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(mreg[i]));   // landed: the wait of kernel row 2 left only DMAs in flight
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          f32x16& acc = nb ? acc1 : acc0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const u32x2b m = mreg[nb * 4 + g];   // 4 bf16: a positive value has a non-zero magnitude and a clear sign bit
+            const bool p0 = (short)(m[0] & 0xffffu) > 0, p1 = (int)m[0] > 0xffff, p2 = (short)(m[1] & 0xffffu) > 0, p3 = (int)m[1] > 0xffff;
+            acc[4 * g] = p0 ? acc[4 * g] : 0.f;
+            acc[4 * g + 1] = p1 ? acc[4 * g + 1] : 0.f;
+            acc[4 * g + 2] = p2 ? acc[4 * g + 2] : 0.f;
+            acc[4 * g + 3] = p3 ? acc[4 * g + 3] : 0.f;
+          }
+          emit(acc, nb, wave_uniform(gs + (size_t)(l - 1) * ba.stride_g_layer));
+        }
+        bias_rows(acc0, acc1);
+      }
+      // ---- acc = gx_s = J_f(x_s)^T gk_s: the reverse Runge-Kutta bookkeeping (targets of fixed_grid.hip, same expressions)
+      const float third = 1.0f / 3.0f;
+      if (s == 3) {
+        // gy = g + gx4; gk3 = (3h/8) g + h gx4; gk2 = (3h/8) g - h gx4; gk1 = (h/8) g + h gx4
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x16& gx = nb ? acc1 : acc0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float g = G[nb][i];
+            float o3 = gx[i] * (0.f + 1.f * h); o3 += g * (0.f + 0.375f * h);
+            float o2 = gx[i] * (0.f + -1.f * h); o2 += g * (0.f + 0.375f * h);
+            float o1 = gx[i] * (0.f + 1.f * h); o1 += g * (0.f + 0.125f * h);
+            float oy = gx[i] * (1.f + 0.f * h); oy += g * (1.f + 0.f * h);
+            gk[2][nb][i] = o3; gk[1][nb][i] = o2; gk[0][nb][i] = o1; G[nb][i] = oy;
+          }
+        }
+      } else if (s == 2) {
+        // gy += gx3; gk2 += h gx3; gk1 -= (h/3) gx3
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x16& gx = nb ? acc1 : acc0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float oy = gx[i] * (1.f + 0.f * h); oy += G[nb][i] * (1.f + 0.f * h);
+            float o2 = gx[i] * (0.f + 1.f * h); o2 += gk[1][nb][i] * (1.f + 0.f * h);
+            float o1 = gx[i] * (0.f + -third * h); o1 += gk[0][nb][i] * (1.f + 0.f * h);
+            G[nb][i] = oy; gk[1][nb][i] = o2; gk[0][nb][i] = o1;
+          }
+        }
+      } else if (s == 1) {
+        // gy += gx2; gk1 += (h/3) gx2
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x16& gx = nb ? acc1 : acc0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float oy = gx[i] * (1.f + 0.f * h); oy += G[nb][i] * (1.f + 0.f * h);
+            float o1 = gx[i] * (0.f + third * h); o1 += gk[0][nb][i] * (1.f + 0.f * h);
+            G[nb][i] = oy; gk[0][nb][i] = o1;
+          }
+        }
+      } else {
+        // stage 1 closes the interval: g(y_n) = gy + gx1 + grad_out[n]  (the next interval's seed is formed from it at its stage 4)
+        // and the seed of interval n-1's stage 4, (h_{n-1}/8) g(y_n), as the per-launch path forms it: term by term
+        f32x16 go[2];
+        load_go(n, go);
+        const float hb = n > 0 ? ba.hdev[n - 1] : 0.0f;
+        const float cs = 0.f + 0.125f * hb;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x16& gx = nb ? acc1 : acc0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float o = gx[i] * (1.f + 0.f * hb); o += G[nb][i] * (1.f + 0.f * hb); o += go[nb][i] * (1.f + 0.f * hb);
+            float sd = gx[i] * cs; sd += G[nb][i] * cs; sd += go[nb][i] * cs;
+            G[nb][i] = o;
+            gk[0][nb][i] = sd;
+          }
+        }
+      }
+    }
+  }
+  // grad z0 (NCHW) and this sample's bias-gradient sums
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float* dst = ba.grad_z0_nchw + ((size_t)b * 64 + mb * 32 + 8 * g + 4 * kq) * kPix + (nb ? P1 : P0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[(size_t)j * kPix] = G[nb][4 * g + j];
+    }
+  __syncthreads();   // every chain folded its five row-sum sets (the last one at its last layer's first kernel row)
+  for (int i = threadIdx.x; i < NL * 64; i += 512) ba.bias_part[(size_t)b * NL * 64 + i] = bsum[i];
+}
+
+// db[l][ch] = sum over samples of bias_part[b][l][ch], in order
+__global__ __launch_bounds__(64) void bias_reduce_kernel(const float* __restrict__ part, int batch, int n_layers, float* const* __restrict__ db) {
+  const int l = blockIdx.x, ch = threadIdx.x;
+  float t = 0.0f;
+  for (int b = 0; b < batch; ++b) t += part[((size_t)b * n_layers + l) * 64 + ch];
+  db[l][ch] = t;
+}
+
+struct DbPack {
+  float* p[ODEHIP_MAX_LAYERS];
+};
+__global__ __launch_bounds__(64) void bias_reduce_pack_kernel(const float* __restrict__ part, int batch, int n_layers, DbPack db) {
+  const int l = blockIdx.x, ch = threadIdx.x;
+  float t = 0.0f;
+  for (int b = 0; b < batch; ++b) t += part[((size_t)b * n_layers + l) * 64 + ch];
+  db.p[l][ch] = t;
+}
+
+int launch_btraj_bf16_rk4(const odehip_convstack* f_dgrad, const float* grad_out_nchw, float* grad_z0_nchw, const float* hdev, int n_times,
+                          int batch, const void* save_h, size_t stride_h_eval, size_t stride_h_layer, void* save_g, size_t stride_g_eval,
+                          size_t stride_g_layer, float* bias_part, float* const* grad_b, hipStream_t stream) {
+  BtrajArgs ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.grad_out_nchw = grad_out_nchw; ba.grad_z0_nchw = grad_z0_nchw; ba.hdev = hdev; ba.w_fused = f_dgrad->w_fused;
+  ba.save_h = (const char*)save_h; ba.save_g = (char*)save_g; ba.bias_part = bias_part;
+  ba.stride_h_eval = stride_h_eval; ba.stride_h_layer = stride_h_layer; ba.stride_g_eval = stride_g_eval; ba.stride_g_layer = stride_g_layer;
+  ba.n_layers = f_dgrad->n_convs; ba.n_steps = n_times - 1; ba.batch = batch;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)btraj_bf16_rk4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  // LDS: tile + ring + [NL][64] sums (the bias slot) + 2 KiB of row sums
+  hipLaunchKernelGGL(btraj_bf16_rk4_kernel, dim3(batch), dim3(512), kFusedLds + 8 * 4 * 16 * 4, stream, ba);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  DbPack db;
+  memset(&db, 0, sizeof(db));
+  for (int l = 0; l < f_dgrad->n_convs; ++l) db.p[l] = grad_b[l];
+  hipLaunchKernelGGL(bias_reduce_pack_kernel, dim3(f_dgrad->n_convs), dim3(64), 0, stream, bias_part, batch, f_dgrad->n_convs, db);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+}  // namespace odehip

@@ -150,9 +150,19 @@ extern "C" size_t odehip_odeint_workspace_bytes(const odehip_convstack* f, int b
   return FixedLayout(f, batch, n_times, method, save_for_backward).total;
 }
 
+// the saved tensors of a forward pass are bf16 "Q4h" written by the whole-trajectory launch (format 1) when: bf16 fused stack,
+// every layer 64 -> 64, rk4, and the persistent switch is on
+static bool bf16_trajectory_ok(const odehip_convstack* f, int method) {
+  if (!f->w_fused || f->ks != 3 || g_debug_flags || !persist_switch_on()) return false;
+  for (int l = 0; l <= f->n_convs; ++l)
+    if (f->channels[l] != 64) return false;
+  return method == ODEHIP_EULER || method == ODEHIP_MIDPOINT || method == ODEHIP_RK4;
+}
+
 extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
                                    int n_times, int batch, float* out_nchw, int save_for_backward, int negate,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+                                   void* workspace, size_t workspace_bytes, int* saved_format_out, void* stream_) {
+  if (saved_format_out) *saved_format_out = 0;
   int rc = check_common(f, method, t_host, n_times, batch, "odeint_fixed");
   ODEHIP_REQUIRE(!(negate && save_for_backward), "odeint_fixed: backward through negated dynamics is not supported");
   if (rc != ODEHIP_OK) return rc;
@@ -177,6 +187,22 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   for (int i = 0; i + 1 < n_times; ++i) hbuf[i] = (float)(t_host[i + 1] - t_host[i]);
   rc = upload_floats(hdev, hbuf, n_times - 1, stream);
   if (rc != ODEHIP_OK) return rc;
+
+  // bf16 compute, 64-channel stack: the whole trajectory as ONE launch with one workgroup per sample -- state and stage derivatives
+  // in registers, activations in LDS (fstack_bf16.hip: ftraj_bf16_kernel).  A training forward (rk4) also saves every stage input
+  // and hidden activation as bf16 for the one-launch reverse sweep (btraj_bf16.hip): saved format 1.
+  if (bf16_trajectory_ok(f, method) && (!save_for_backward || method == ODEHIP_RK4)) {
+    if (save_for_backward) {
+      rc = launch_ftraj_bf16_saving(f, z0_nchw, out_nchw, hdev, n_times, batch, L.p(ws, L.off_xin), L.st, L.p(ws, L.off_hid),
+                                    (size_t)L.NH * L.hid, L.hid, stream);
+      if (rc == ODEHIP_OK && saved_format_out) *saved_format_out = 1;
+      ODEHIP_REQUIRE(saved_format_out, "odeint_fixed: saved_format_out is required with save_for_backward");
+    } else {
+      rc = launch_ftraj_bf16(f, method, z0_nchw, out_nchw, hdev, n_times, batch, negate, stream);
+    }
+    if (rc == ODEHIP_OK) persist_count_launch();
+    return rc;
+  }
 
   // One launch for the whole trajectory when the dynamics are the 64-channel fp32 stack: the loop below then only RECORDS its
   // layers (with save_for_backward only the destinations of the hidden layers differ).
@@ -289,9 +315,10 @@ static int guard_gradients(PersistScope& persist, const odehip_convstack* f, int
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, int method,
                                             const double* t_host, int n_times, int batch, const float* grad_out_nchw,
-                                            float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, void* workspace,
-                                            size_t workspace_bytes, void* stream_) {
+                                            float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, int saved_format,
+                                            void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_common(f, method, t_host, n_times, batch, "odeint_fixed_backward");
+  ODEHIP_REQUIRE(saved_format == 0 || saved_format == 1, "odeint_fixed_backward: unknown saved format %d", saved_format);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(f_dgrad && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace, "odeint_fixed_backward: null pointer");
   for (int l = 0; l <= f->n_convs; ++l)
@@ -311,6 +338,46 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
   float* gy = L.p(ws, L.off_gy);
   float* gbuf[2] = {L.p(ws, L.off_g2), L.p(ws, L.off_g2 + L.st)};
 
+  if (saved_format == 1 && n_times > 1) {
+    // ---- the forward was the whole-trajectory bf16 launch: ONE launch for the reverse sweep (gradient state in registers, every
+    // conv-output gradient stored as bf16 Q4h), then one weight-gradient launch per layer on the bf16 operands
+    ODEHIP_REQUIRE(method == ODEHIP_RK4 && f->w_fused && f_dgrad->w_fused, "odeint_fixed_backward: saved format 1 belongs to the fused bf16 rk4 path");
+    float* bias_part = L.p(ws, L.off_g2);   // [B][NL][64] fp32: fits the two state-sized scratch tensors of the per-launch path
+    rc = launch_btraj_bf16_rk4(f_dgrad, grad_out_nchw, grad_z0_nchw, hdev, n_times, batch, L.p(ws, L.off_hid), (size_t)NH * L.hid, L.hid,
+                               L.p(ws, L.off_gp), (size_t)(NH + 1) * L.hid, L.hid, bias_part, grad_b, stream);
+    if (rc != ODEHIP_OK) return rc;
+    const int n_eval = (n_times - 1) * S;
+    ODEHIP_REQUIRE(n_eval <= 32 * 64, "odeint backward: too many evaluations (%d)", n_eval);
+    WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
+    float* slabs = L.p(ws, L.off_slab);
+    float* db_scratch = L.p(ws, L.off_gy);   // the reduce kernel's bias output (zeros here: the sweep summed the bias gradients)
+    for (int l = 0; l < NL; ++l) {
+      for (int o = 0; o < 4 * n_eval; o += 32) {
+        PtrPack pk;
+        const int m = 4 * n_eval - o < 32 ? 4 * n_eval - o : 32;
+        for (int i = 0; i < m; ++i) {
+          const int e = (o + i) / 4, field = (o + i) & 3;
+          unsigned long long v = 0;
+          if (field == 0) v = (unsigned long long)(uintptr_t)((char*)L.p(ws, L.off_gp) + ((size_t)e * (NH + 1) + l) * L.hid);
+          else if (field == 1)
+            v = (unsigned long long)(uintptr_t)(l > 0 ? (char*)L.p(ws, L.off_hid) + ((size_t)e * NH + (l - 1)) * L.hid
+                                                      : (char*)L.p(ws, L.off_xin) + (size_t)e * L.st);
+          else if (field == 2) {
+            const float one = 1.0f;
+            unsigned u32;
+            memcpy(&u32, &one, 4);
+            v = u32;
+          }
+          pk.v[i] = v;
+        }
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
+      }
+      rc = launch_wgrad_q4h(table, n_eval, batch, kEsplit, slabs, grad_w[l], db_scratch, stream);
+      if (rc != ODEHIP_OK) return rc;
+    }
+    return ODEHIP_OK;
+  }
+  ODEHIP_REQUIRE(saved_format == 0 || n_times == 1, "odeint_fixed_backward: bad saved format");
   rc = odehip_nchw_to_q4(grad_out_nchw, L.go(ws, 0), n_times * batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
   if (n_times == 1) {

@@ -17,36 +17,12 @@
 // hidden activations (fp32, for a later backward).  The last layer ends in the shared fused epilogue (conv_common.h).
 // Used when every layer is 64 -> 64 (the ODEConvGRU dynamics) and a fused weight image is present; batches below 256 leave
 // CUs idle -- at B = 64 one f evaluation still takes ~1/3 of five bf16 launches.
-#include "conv_common.h"
+#include <string.h>
+
+#include "fused_bf16.h"
 
 namespace odehip {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
-  return __builtin_bit_cast(unsigned, v);
-}
-
-constexpr int kFS = 144;                   // bytes per pixel of an activation tile (64 ch bf16 + 16 pad)
-constexpr int kFTile = 18 * 18 * kFS;      // 46,656 B
-constexpr int kFUnit = 3 * 8192;           // one kernel row (3 taps) of one layer
-constexpr int kFStages = 3;
-constexpr int kFBias = ODEHIP_MAX_LAYERS * 64 * 4;  // every layer's bias, staged once (a global load per layer would sit in front of the ring's vmcnt waits)
-constexpr int kFusedLds = kFTile + kFStages * kFUnit + kFBias;
-
-// issued without the compiler's own s_waitcnt bookkeeping: the ring's counted waits cover it (see wait_younger)
-__device__ __forceinline__ f32x4 gload_untracked(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // n (wave-uniform) = vector-memory operations this wave issued AFTER the ring unit it is about to read: 3 (the next unit's
 // DMAs) + 8 per hidden-layer store set + 8 per prefetched mask set
 __device__ __forceinline__ void wait_younger(int n) {
@@ -209,6 +185,281 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
   // ---- last layer: the shared fused epilogue (stage combine, error partials, reverse-sweep targets, ...)
   epilogue(fa.last, acc0, b, mb, P0, kq, wave, b * 16 + wave);
   epilogue(fa.last, acc1, b, mb, P1, kq, wave, b * 16 + 8 + wave);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// ftraj_bf16_kernel<METHOD, SAVE> -- a WHOLE fixed-grid trajectory (every interval, every Runge-Kutta stage, every layer of
+// every evaluation of f) in ONE launch, one workgroup per sample: between two evaluations nothing leaves the CU.  The solver
+// state y and the stage derivatives k_1 .. k_{S-1} stay in REGISTERS (fp32, the accumulator layout: lane = (pixel, channel-quad
+// pair)), the next stage's input y + h*sum c_j k_j is formed there and written straight into the LDS activation tile as bf16 --
+// the per-evaluation launch above pays for that hand-over with a launch boundary, an fp32 round trip of x through HBM and a
+// staging pass (about 10 of its 21 us).  The weight ring simply keeps cycling through the 3*NL units of f; the result frames
+// (fp32 NCHW) and, with SAVE, every stage input and hidden activation (bf16 "Q4h": what the backward sweep's masks and the
+// weight-gradient kernel consume) are stored asynchronously -- counted in the ring's vmcnt waits, never drained.  Arithmetic and
+// its order are those of the per-evaluation path (same bf16 roundings, same stage-combine expressions as
+// conv_common.h::epilogue), so the trajectories are bit-identical.
+struct TrajArgs {
+  const float* z0_nchw;                  // (B,64,16,16)
+  float* out_nchw;                       // (T,B,64,16,16); frame 0 is written by the caller
+  const float* hdev;                     // [n_steps] step sizes (fp32, as they meet the state)
+  const void* w_fused;
+  const float* bias[ODEHIP_MAX_LAYERS];
+  int n_layers, n_steps, batch;
+  float k_scale;                         // -1: negated dynamics (decreasing time grid)
+  // SAVE: base of the stage inputs / hidden activations, slot strides in bytes (evaluation e = n*S + s; layer l)
+  char* save_x;                          // [e] : Q4h of x_s (s = 0: y_n)
+  char* save_h;                          // [e][l] : Q4h of the ReLU output of conv l < NL-1
+  unsigned long long stride_x, stride_h_eval, stride_h_layer;
+};
+
+// the stage programs of fixed_grid.hip (torchdiffeq _impl/fixed_grid.py; rk4 = the 3/8 rule), compile-time constants here: per
+// stage, how many earlier k enter its combine (n_prev) and the weights of k_1 .. k_{n_prev} and (last) of the stage's own k
+template <int METHOD> struct StageProgram;
+template <> struct StageProgram<ODEHIP_EULER> {
+  static constexpr int S = 1;
+  static constexpr int n_prev[4] = {0, 0, 0, 0};
+  static constexpr float c[4][4] = {{1.0f, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+};
+template <> struct StageProgram<ODEHIP_MIDPOINT> {
+  static constexpr int S = 2;
+  static constexpr int n_prev[4] = {0, 0, 0, 0};   // the midpoint rule's result does not use k1
+  static constexpr float c[4][4] = {{0.5f, 0, 0, 0}, {1.0f, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+};
+template <> struct StageProgram<ODEHIP_RK4> {
+  static constexpr int S = 4;
+  static constexpr int n_prev[4] = {0, 1, 2, 3};
+  static constexpr float c[4][4] = {{1.0f / 3.0f, 0, 0, 0}, {-(1.0f / 3.0f), 1.0f, 0, 0}, {1.0f, -1.0f, 1.0f, 0}, {0.125f, 0.375f, 0.375f, 0.125f}};
+};
+
+template <int METHOD, bool SAVE>
+__global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
+  typedef StageProgram<METHOD> Prog;
+  constexpr int S = Prog::S;
+  constexpr int NK = Prog::n_prev[S - 1];   // stage derivatives that must be kept (rk4: 3, midpoint / euler: 0)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const act = smem;
+  char* const ring = smem + kFTile;
+  float* const bias_l = (float*)(smem + kFTile + kFStages * kFUnit);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  const int NL = ta.n_layers, UE = NL * 3;
+  const long long U = (long long)ta.n_steps * S * UE;   // ring units of the whole trajectory
+
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(ta.w_fused, (unsigned)(UE * kFUnit));
+  const int vw = lane * 16;
+  auto issue = [&](int ue, int stage) {  // unit `ue` of f (0 .. UE-1) into ring stage `stage`: three 1-KiB pieces per wave
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      dma16(rw, ring + stage * kFUnit + (wave * 3 + j) * 1024, vw, ue * kFUnit + (wave * 3 + j) * 1024);
+  };
+  issue(0, 0);
+  issue(1 % UE, 1);
+
+  for (int i = threadIdx.x; i < NL * 64; i += 512) bias_l[i] = ta.bias[i >> 6] ? ta.bias[i >> 6][i & 63] : 0.0f;
+  for (int i = threadIdx.x; i < 68 * 9; i += 512) {  // zero border of the tile
+    const int p = i / 9, c16 = i % 9;
+    int row, col;
+    if (p < 18) { row = 0; col = p; }
+    else if (p < 36) { row = 17; col = p - 18; }
+    else if (p < 52) { row = p - 36 + 1; col = 0; }
+    else { row = p - 52 + 1; col = 17; }
+    *(f32x4*)(act + (row * 18 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int i32 = lane & 31, kq = lane >> 5;
+  const int px = i32 & 15, pyl = i32 >> 4;
+  const int mb = wave & 1, row0 = (wave >> 1) * 4 + pyl;
+  const int P0 = row0 * 16 + px, P1 = P0 + 32;
+  const char* const in = act + ((row0 + 1) * 18 + px + 1) * kFS + kq * 16;
+
+  // solver state: y[nb][4g + j] = channel 32 mb + 8 g + 4 kq + j of pixel (nb ? P1 : P0) -- the accumulator layout
+  f32x16 y[2], k[NK > 0 ? NK : 1][2];
+  // channels of quad Q = 8 mb + 2 g + kq as bf16: into the activation tile and, if `dst` (wave-uniform: this sample's Q4h tensor),
+  // into HBM -- one lane offset, the quads 4 KiB apart
+  const unsigned q4h_off = (unsigned)(((mb * 8 + kq) * kPix + P0) * 8);
+  auto emit = [&](const f32x16& v, int nb, char* dst) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int Q = mb * 8 + 2 * g + kq;
+      const u32x2 pk = {pk_bf16(v[4 * g], v[4 * g + 1]), pk_bf16(v[4 * g + 2], v[4 * g + 3])};
+      *(u32x2*)(act + ((row0 + 2 * nb + 1) * 18 + px + 1) * kFS + Q * 8) = pk;
+      if (SAVE && dst) *(u32x2*)(dst + (q4h_off + (unsigned)(g * 2 * kPix * 8 + nb * 32 * 8))) = pk;
+    }
+  };
+  char* const save_x = SAVE ? wave_uniform(ta.save_x + (size_t)b * kQ4hSample) : nullptr;
+  char* const save_h = SAVE ? wave_uniform(ta.save_h + (size_t)b * kQ4hSample) : nullptr;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float* src = ta.z0_nchw + ((size_t)b * 64 + mb * 32 + 8 * g + 4 * kq) * kPix + (nb ? P1 : P0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[nb][4 * g + j] = src[(size_t)j * kPix];
+    }
+    emit(y[nb], nb, save_x);
+  }
+
+  long long u = 0;
+  int frame_pending = 0;   // the previous stage stored a result frame: 32 more stores younger than the first two units' DMAs (wave-uniform)
+  f32x16 acc0, acc1;
+  for (int n = 0; n < ta.n_steps; ++n) {
+    const float h = ta.hdev[n];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const size_t ev = (size_t)n * S + s;
+      for (int e = 0; e < NL; ++e) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r, ++u) {
+          // unit u landed?  Younger than its DMAs: the next unit's three DMAs and -- for the first two units of a layer -- what was
+          // stored after the previous layer: its saved activation (8 stores per lane) or, after a stage, the saved stage input
+          // (8) and, after an interval's last stage, the result frame (32)
+          // (one two-way branch with immediates: a chain of alternative waits in this loop costs the register allocator its footing)
+          if (u == 0 || u + 1 >= U) wait_le<0>();
+          else if (e == 0 && r < 2 && frame_pending) wait_le<3 + 32 + (SAVE ? 8 : 0)>();
+          else if (r < 2) wait_le<3 + (SAVE ? 8 : 0)>();
+          else wait_le<3>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (u + 2 < U) issue((int)((u + 2) % UE), (r + 2) % 3);
+          if (r == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 b0 = *(const f32x4*)(bias_l + e * 64 + mb * 32 + 8 * g + 4 * kq);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { acc0[4 * g + j] = b0[j]; acc1[4 * g + j] = b0[j]; }
+            }
+          }
+          u32x4 xc[2][4];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) xc[nb][cb] = *(const u32x4*)(in + ((r - 1) * 18 + nb * 36) * kFS + cb * 32);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const char* wb = ring + r * kFUnit + c * 8192 + mb * 1024 + vw;
+            bf16x8 w[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) w[cb] = *(const bf16x8*)(wb + cb * 2048);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) {
+                u32x4 xs = xc[nb][cb];
+                if (c == 0) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) xs[j] = __builtin_amdgcn_update_dpp(0u, xc[nb][cb][j], 0x111, 0xf, 0xf, true);
+                } else if (c == 2) {
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) xs[j] = __builtin_amdgcn_update_dpp(0u, xc[nb][cb][j], 0x101, 0xf, 0xf, true);
+                }
+                const bf16x8 xv = __builtin_bit_cast(bf16x8, xs);
+                if (nb == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb], xv, acc0, 0, 0, 0);
+                else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[cb], xv, acc1, 0, 0, 0);
+              }
+            }
+          }
+        }
+        if (e == 0) frame_pending = 0;
+        // every wave has read the tile: rewrite it in place (hidden layer: ReLU; last layer: the next stage input / new state)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (e < NL - 1) {
+          char* const dst = SAVE ? wave_uniform(save_h + ev * ta.stride_h_eval + (size_t)e * ta.stride_h_layer) : nullptr;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x16 v = nb ? acc1 : acc0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            emit(v, nb, dst);
+          }
+        }
+      }
+      // ---- stage combine (conv_common.h::epilogue, combine == 1): kc = k_scale * f(x_s);  out = y + h * (c[n_prev] kc + sum_j c[j] k_j)
+      const bool final_stage = s == S - 1;
+      // the next evaluation's input: x_{s+1} of this interval, or y_{n+1} (= x_1 of the next interval; not needed after the last)
+      char* const dst = SAVE ? wave_uniform(save_x + (ev + 1) * ta.stride_x) : nullptr;
+      const bool last_eval = final_stage && n + 1 == ta.n_steps;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const f32x16& acc = nb ? acc1 : acc0;
+        f32x16 o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 kc = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+          kc *= ta.k_scale;
+          f32x4 sa = kc * Prog::c[s][Prog::n_prev[s]];
+#pragma unroll
+          for (int j = 0; j < NK; ++j)
+            if (j < Prog::n_prev[s]) {
+              const f32x4 kp = {k[j][nb][4 * g], k[j][nb][4 * g + 1], k[j][nb][4 * g + 2], k[j][nb][4 * g + 3]};
+              sa += kp * Prog::c[s][j];
+            }
+          const f32x4 yv = {y[nb][4 * g], y[nb][4 * g + 1], y[nb][4 * g + 2], y[nb][4 * g + 3]};
+          const f32x4 ov = yv + sa * h;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[4 * g + j] = ov[j];
+          if (s < NK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) k[s < NK ? s : 0][nb][4 * g + j] = kc[j];
+          }
+        }
+        if (final_stage) {
+          y[nb] = o;
+          float* fr = ta.out_nchw + ((size_t)(n + 1) * ta.batch + b) * 64 * kPix + (nb ? P1 : P0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fr[(size_t)(mb * 32 + 8 * g + 4 * kq + j) * kPix] = o[4 * g + j];
+        }
+        emit(o, nb, last_eval ? nullptr : dst);
+      }
+      if (final_stage) frame_pending = 1;
+    }
+  }
+}
+
+static void traj_args(TrajArgs& ta, const odehip_convstack* f, const float* z0_nchw, float* out_nchw, const float* hdev, int n_times,
+                      int batch, int negate) {
+  memset(&ta, 0, sizeof(ta));
+  ta.z0_nchw = z0_nchw; ta.out_nchw = out_nchw; ta.hdev = hdev; ta.w_fused = f->w_fused;
+  for (int l = 0; l < f->n_convs; ++l) ta.bias[l] = f->bias[l];
+  ta.n_layers = f->n_convs; ta.n_steps = n_times - 1; ta.batch = batch;
+  ta.k_scale = negate ? -1.0f : 1.0f;
+}
+
+template <int METHOD, bool SAVE>
+static int launch_ftraj(const TrajArgs& ta, int batch, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)ftraj_bf16_kernel<METHOD, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ftraj_bf16_kernel<METHOD, SAVE>), dim3(batch), dim3(512), kFusedLds, stream, ta);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+int launch_ftraj_bf16(const odehip_convstack* f, int method, const float* z0_nchw, float* out_nchw, const float* hdev, int n_times,
+                      int batch, int negate, hipStream_t stream) {
+  TrajArgs ta;
+  traj_args(ta, f, z0_nchw, out_nchw, hdev, n_times, batch, negate);
+  if (method == ODEHIP_EULER) return launch_ftraj<ODEHIP_EULER, false>(ta, batch, stream);
+  if (method == ODEHIP_MIDPOINT) return launch_ftraj<ODEHIP_MIDPOINT, false>(ta, batch, stream);
+  if (method == ODEHIP_RK4) return launch_ftraj<ODEHIP_RK4, false>(ta, batch, stream);
+  set_error("ftraj_bf16: unknown method %d", method);
+  return ODEHIP_EINVAL;
+}
+
+// rk4 training forward: also saves every stage input (slot e = n*4 + s of save_x) and hidden activation (save_h) as bf16 Q4h
+int launch_ftraj_bf16_saving(const odehip_convstack* f, const float* z0_nchw, float* out_nchw, const float* hdev, int n_times, int batch,
+                             void* save_x, size_t stride_x, void* save_h, size_t stride_h_eval, size_t stride_h_layer,
+                             hipStream_t stream) {
+  TrajArgs ta;
+  traj_args(ta, f, z0_nchw, out_nchw, hdev, n_times, batch, 0);
+  ta.save_x = (char*)save_x; ta.save_h = (char*)save_h;
+  ta.stride_x = stride_x; ta.stride_h_eval = stride_h_eval; ta.stride_h_layer = stride_h_layer;
+  return launch_ftraj<ODEHIP_RK4, true>(ta, batch, stream);
 }
 
 // fused image of executed layer `e`: [tap][cb][mb][h][co32][8]

@@ -123,6 +123,9 @@ struct FusedArgs {
   ConvArgs last;                           // epilogue of the last executed layer (qout = 16)
 };
 int launch_fstack_bf16(const FusedArgs& fa, int batch, hipStream_t stream);
+// whole fixed-grid trajectory of a fused-bf16 64-channel stack in one launch (forward only, nothing saved)
+int launch_ftraj_bf16(const odehip_convstack* f, int method, const float* z0_nchw, float* out_nchw, const float* hdev, int n_times,
+                      int batch, int negate, hipStream_t stream);
 extern int g_debug_flags;
 extern unsigned long long* g_debug_buf;
 
@@ -156,6 +159,14 @@ struct WgradPair {
 // bf16 = true: operands rounded to bf16 (fp32 accumulation), for stacks running in bf16 compute mode
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                  int cin, hipStream_t stream, bool bf16 = false);
+int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db_scratch,
+                     hipStream_t stream);
+int launch_ftraj_bf16_saving(const odehip_convstack* f, const float* z0_nchw, float* out_nchw, const float* hdev, int n_times, int batch,
+                             void* save_x, size_t stride_x, void* save_h, size_t stride_h_eval, size_t stride_h_layer,
+                             hipStream_t stream);
+int launch_btraj_bf16_rk4(const odehip_convstack* f_dgrad, const float* grad_out_nchw, float* grad_z0_nchw, const float* hdev, int n_times,
+                          int batch, const void* save_h, size_t stride_h_eval, size_t stride_h_layer, void* save_g, size_t stride_g_eval,
+                          size_t stride_g_layer, float* bias_part, float* const* grad_b, hipStream_t stream);
 int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
                       int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
                       hipStream_t stream);

@@ -40,6 +40,11 @@ class PersistScope {
   bool launched_ = false;
 };
 
+// Whole-trajectory launches that need no cross-workgroup hand-off (bf16: one workgroup per sample) obey the same on/off switch
+// (odehip_set_persistent_trajectory / ODEHIP_PERSISTENT=0) and are counted by odehip_persistent_trajectory_launches().
+bool persist_switch_on();
+void persist_count_launch();
+
 // host-side look at the sticky error word of the persistent launches (0 = none); clear != 0 resets it and disables the path
 unsigned persist_error(bool clear);
 

@@ -95,6 +95,18 @@ __global__ void persist_guard_kernel(const GuardArgs a) {
       a.p[r][i] = __builtin_nanf("");
 }
 
+bool persist_switch_on() {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  if (g_persist.enabled == 0) return false;
+  static const bool env_off = [] { const char* e = getenv("ODEHIP_PERSISTENT"); return e && e[0] == '0'; }();
+  return !env_off;
+}
+
+void persist_count_launch() {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  ++g_persist.launches;
+}
+
 unsigned persist_error(bool clear) {
   PersistState& P = g_persist;
   if (!P.host_err) return 0;

@@ -518,6 +518,94 @@ __global__ __launch_bounds__(256, 1) void wgrad64_bf16_kernel(const WgradPair* _
   if (tid < 64) slab[64 * 64 * 9 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
 }
 
+// ---- the same with operands that are already bf16 (Q4h), for the whole-trajectory bf16 training path
+__global__ __launch_bounds__(256, 1) void wgrad64_q4h_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                              float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                              int a_quads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const gt = smem;
+  char* const at = smem + kWG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, es = blockIdx.y;
+  const int mb = wave & 1, nb = wave >> 1;
+
+  // zero border of the A tile (68 pixels x 128 data bytes)
+  for (int i = tid; i < 68 * 8; i += 256) {
+    const int p = i >> 3, c16 = i & 7;
+    int row, col;
+    if (p < 18) { row = 0; col = p; }
+    else if (p < 36) { row = 17; col = p - 18; }
+    else if (p < 52) { row = p - 36 + 1; col = 0; }
+    else { row = p - 52 + 1; col = 17; }
+    *(f32x4*)(at + (row * 18 + col) * kWS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  f32x16w acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  // per-lane bases of the transposed reads: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 of the group's 16
+  const int grp = lane >> 4, l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, h = lane >> 5;
+  const char* gbase = gt + (8 * h + q) * kWS + (mb * 32 + 16 * (grp & 1) + 4 * p4) * 2;
+  const char* abase = at + (8 * h + q) * kWS + (nb * 32 + 16 * (grp & 1) + 4 * p4) * 2;  // + (row*18 + col offset) * kWS per tap
+
+  // operands are ALREADY bf16 ("Q4h": [sample][quad][pixel] x 4 bf16 = 8 bytes; written by ftraj_bf16_kernel<RK4, SAVE> and
+  // btraj_bf16_rk4_kernel): half the HBM bytes of the fp32 kernel above -- which is what bounds it -- and no conversion
+  u32x2w gv[16], av[16];
+  auto prefetch = [&](int e) {
+    const WgradPair pr = table[e];
+    const u32x2w* g = (const u32x2w*)pr.g + ((size_t)b * g_quads + g_quad0) * kPix + tid;
+    const u32x2w* a = (const u32x2w*)pr.a + ((size_t)b * a_quads + a_quad0) * kPix + tid;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gv[i] = g[i * 256];
+      av[i] = a[i * 256];
+    }
+  };
+  if (es < n_eval) prefetch(es);
+  for (int e = es; e < n_eval; e += esplit) {
+    __syncthreads();  // every wave is done with the previous evaluation's tiles
+    {
+      const int prow = tid >> 4, pcol = tid & 15;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {   // quad i of pixel tid
+        *(u32x2w*)(gt + tid * kWS + i * 8) = gv[i];
+        *(u32x2w*)(at + ((prow + 1) * 18 + pcol + 1) * kWS + i * 8) = av[i];
+      }
+    }
+    __syncthreads();
+    if (e + esplit < n_eval) prefetch(e + esplit);  // in flight while this evaluation is multiplied
+#pragma unroll 2
+    for (int y = 0; y < 16; ++y) {
+      const bf16x8w gf = tr_pair(gbase + y * 16 * kWS);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3, dx = t % 3;  // tile coordinates: row y + dy, column x + dx (border included)
+        const bf16x8w af = tr_pair(abase + ((y + dy) * 18 + dx) * kWS);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, af, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  float* slab = slabs + (size_t)(b * esplit + es) * (64 * 64 * 9 + 64);
+  {
+    const int n = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = nb * 32 + n;
+        slab[((size_t)co * 64 + ci) * 9 + t] = acc[t][r];
+      }
+  }
+  if (tid < 64) slab[64 * 64 * 9 + tid] = 0.0f;   // the bias gradient of this path comes from the backward sweep (unrounded fp32)
+}
+
+
 // ---- the same for the 5x5 convs of the ConvGRU cell: tap rows [TY0, TY0+NTY) per launch (10 + 10 + 5 taps) so the accumulators
 // fit; A tile [20][20][64] with a 2-pixel zero border.  Slab layout and reduction of wgrad_tile_kernel.
 template <int KS, int TY0, int NTY>
@@ -666,6 +754,21 @@ int launch_wgrad_bf16(const WgradPair* table_dev, int n_eval, int batch, int esp
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db, cin,
                          co0, ci0);
     }
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+// operands in Q4h (bf16); db is NOT written (db_scratch receives the zeros of the slabs): the caller sums the bias gradient itself
+int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db_scratch,
+                     hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_q4h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int sf = 64 * 64 * 9 + 64;
+  hipLaunchKernelGGL(wgrad64_q4h_kernel, dim3(batch, esplit), dim3(256), kWgradBf16Lds, stream, table_dev, n_eval, esplit, slabs, 0, 16, 0, 16);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db_scratch, 64, 0, 0);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

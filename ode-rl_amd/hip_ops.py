@@ -410,8 +410,11 @@ def odeint_fixed(stack, method, z0, t, save=False, negate=False):
         ws = workspace(("odeint", b, n, m, tuple(desc.channels)), nbytes, z0.device)
     out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
     tarr = (ctypes.c_double * n)(*t64)
+    fmt = ctypes.c_int(0)
     _lib.check(lib.odehip_odeint_fixed(ctypes.byref(desc), m, _ptr(z0), tarr, n, b, _ptr(out), int(save), int(bool(negate)), _ptr(ws),
-                                       ws.numel(), _stream()))
+                                       ws.numel(), ctypes.byref(fmt), _stream()))
+    if save:
+        ws._odehip_saved_format = int(fmt.value)   # how the workspace holds the saved tensors (the backward call must be told)
     return (out, ws) if save else out
 
 
@@ -432,8 +435,8 @@ def odeint_fixed_backward(stack, method, t, batch, grad_out, ws):
     gb_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbs])
     tarr = (ctypes.c_double * n)(*t64)
     _lib.check(_lib.load().odehip_odeint_fixed_backward(ctypes.byref(desc), ctypes.byref(dg), _lib.METHODS[method], tarr, n,
-                                                        batch, _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr, _ptr(ws), ws.numel(),
-                                                        _stream()))
+                                                        batch, _ptr(grad_out), _ptr(gz0), gw_arr, gb_arr,
+                                                        int(getattr(ws, "_odehip_saved_format", 0)), _ptr(ws), ws.numel(), _stream()))
     return gz0, gws, gbs
 
 

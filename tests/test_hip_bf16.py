@@ -199,3 +199,79 @@ def test_config4_bf16_39_intervals(cuda, bf16_mode):
     for i, (c, gw, gb) in enumerate(zip(convs, rg[1:6], rg[6:])):
         errs += [record(f"config4.grad_w{i}", rel_l2(c.weight.grad, gw)), record(f"config4.grad_b{i}", rel_l2(c.bias.grad, gb))]
     assert max(errs) <= 5e-3, errs
+
+
+@pytest.mark.parametrize("method,batch,n_times", [("rk4", 64, 10), ("rk4", 3, 40), ("midpoint", 130, 5), ("euler", 7, 4)])
+def test_whole_trajectory_launch_is_bit_identical_to_per_evaluation_launches(cuda, bf16_mode, method, batch, n_times):
+    """bf16 inference: the whole trajectory in ONE launch (one workgroup per sample, state and stage derivatives in registers,
+    activations in LDS; ftraj_bf16_kernel) against one fused launch per evaluation of f: same bf16 roundings and the same
+    stage-combine expressions, so the trajectories must be equal bit for bit; and against the bf16-emulating oracle."""
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    lib = ode_rl_amd._lib.load()
+    f, sd = _f(seed=3)
+    f = f.to(cuda)
+    z0 = torch.randn(batch, 64, 16, 16, generator=torch.Generator().manual_seed(batch)) * 0.5
+    t = torch.arange(n_times, 2 * n_times, dtype=torch.float64) / (2 * n_times)
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        with torch.no_grad():
+            ref = ode_rl_amd.odeint(f, z0.to(cuda), t, method=method)
+            lib.odehip_set_persistent_trajectory(1)
+            n0 = lib.odehip_persistent_trajectory_launches()
+            for _ in range(2):
+                out = ode_rl_amd.odeint(f, z0.to(cuda), t, method=method)
+        assert lib.odehip_persistent_trajectory_launches() == n0 + 2, "the whole-trajectory launch did not run"
+        assert torch.equal(out, ref)
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
+    if batch <= 8:
+        ws, bs = rm.split_convnet_state(sd, "gradient_net.")
+        with torch.no_grad():
+            emu = torchdiffeq_ref.odeint(rm.ode_func(ws, bs, compute_dtype="bf16"), z0, t, method=method)
+        assert record(f"bf16.traj.{method}.T{n_times}.increment", rel_l2(out.cpu()[1:] - z0, emu[1:] - z0)) <= 1e-3
+
+
+@pytest.mark.parametrize("batch,n_times", [(3, 4), (64, 10), (5, 40)])
+def test_whole_trajectory_training_matches_per_evaluation_launches(cuda, bf16_mode, batch, n_times):
+    """bf16 rk4 TRAINING step: saving forward + reverse sweep as one launch each (activations and conv-output gradients saved
+    as bf16, gradient state in registers) + weight gradients on the bf16 operands, against the per-evaluation path (fp32 saves,
+    bookkeeping in the conv epilogues).  Same bf16 roundings, same MFMA order, same bookkeeping expressions: the trajectory and
+    grad z0 are equal bit for bit, the weight gradients to 1e-6 (observed: equal, or one element off by an ulp), the bias
+    gradients -- summed in a different fixed order -- to 1e-5 (observed 1e-7)."""
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    f, _ = _f(seed=4)
+    f = f.to(cuda)
+    g = torch.Generator().manual_seed(100 + batch)
+    z0 = (torch.randn(batch, 64, 16, 16, generator=g) * 0.5).to(cuda)
+    t = torch.arange(n_times, 2 * n_times, dtype=torch.float64) / (2 * n_times)
+    gout = torch.randn(n_times, batch, 64, 16, 16, generator=g).to(cuda)
+
+    def run():
+        f.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        out = ode_rl_amd.odeint(f, z, t, method="rk4")
+        out.backward(gout)
+        convs = [m for m in f.gradient_net if isinstance(m, torch.nn.Conv2d)]
+        return out.detach().clone(), z.grad.clone(), [c.weight.grad.clone() for c in convs], [c.bias.grad.clone() for c in convs]
+
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        ref = run()
+        lib.odehip_set_persistent_trajectory(1)
+        n0 = lib.odehip_persistent_trajectory_launches()
+        got = run()
+        assert lib.odehip_persistent_trajectory_launches() == n0 + 1, "the whole-trajectory saving forward did not run"
+        again = run()
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
+    assert torch.equal(got[0], ref[0])
+    assert torch.equal(got[1], ref[1]), record(f"bf16.train.gz0.B{batch}", rel_l2(got[1], ref[1]))
+    for l, (a, b) in enumerate(zip(got[2], ref[2])):
+        assert record(f"bf16.train.gw{l}.B{batch}", rel_l2(a, b)) <= 1e-6
+    for l, (a, b) in enumerate(zip(got[3], ref[3])):
+        assert record(f"bf16.train.gb{l}.B{batch}", rel_l2(a, b)) <= 1e-5
+    for a, b in zip([again[0], again[1]] + again[2] + again[3], [got[0], got[1]] + got[2] + got[3]):
+        assert torch.equal(a, b)     # deterministic
