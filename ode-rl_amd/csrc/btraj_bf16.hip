@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
   char* const act = smem;
   char* const ring = smem + kFTile;
   float* const bsum = (float*)(smem + kFTile + kFStages * kFUnit);   // [NL][64] bias-gradient sums of this sample (the bias slot of the layout)
-  float* const bpart = bsum + ODEHIP_MAX_LAYERS * 64;                // [8 waves][4 rows of 16 lanes][16 channels]: row sums of one layer
+  float* const bpart = bsum + ODEHIP_MAX_LAYERS * 64;                // [NL][8 waves][4 rows of 16 lanes][16 channels]: running row sums
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
   issue(1 % UE, 1);
 
   for (int i = threadIdx.x; i < NL * 64; i += 512) bsum[i] = 0.0f;
+  for (int i = threadIdx.x; i < NL * 512; i += 512) bpart[i] = 0.0f;
   for (int i = threadIdx.x; i < 68 * 9; i += 512) {  // zero border of the tile
     const int p = i / 9, c16 = i % 9;
     int row, col;
@@ -84,12 +85,19 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
       const int Q = mb * 8 + 2 * g + kq;
       const u32x2 pk = {pk_bf16(v[4 * g], v[4 * g + 1]), pk_bf16(v[4 * g + 2], v[4 * g + 3])};
       *(u32x2*)(act + ((row0 + 2 * nb + 1) * 18 + px + 1) * kFS + Q * 8) = pk;
+#ifndef BTRAJ_ABLATE_no_gstore
       *(u32x2*)(dst + (q4h_off + (unsigned)(g * 2 * kPix * 8 + nb * 32 * 8))) = pk;
+#endif
     }
   };
   // bias gradient of one conv output: sum over this wave's 64 pixels of the UNROUNDED gradient -- DPP sums inside the rows of 16
-  // lanes, the four row totals of each of the 16 channel registers parked in LDS; folded in a fixed order after the next barrier
-  auto bias_rows = [&](const f32x16& v0, const f32x16& v1) {
+  // lanes, then lane 15 of each row adds the row total to the row's OWN running sum in LDS (one writer per word, evaluations in
+  // order: deterministic, no barrier needed); the rows are folded once, at the end of the kernel
+  auto bias_rows = [&](const f32x16& v0, const f32x16& v1, int layer) {
+#ifdef BTRAJ_ABLATE_no_bias
+    return;
+#endif
+    float* slot = bpart + ((layer * 8 + wave) * 4 + (lane >> 4)) * 16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float v = v0[i] + v1[i];
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
       v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));  // row_shr:2
       v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));  // row_shr:4
       v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));  // row_shr:8
-      if ((lane & 15) == 15) bpart[(wave * 4 + (lane >> 4)) * 16 + i] = v;   // lane 15 of a row holds the row's total
+      if ((lane & 15) == 15) slot[i] += v;   // lane 15 of a row holds the row's total
     }
   };
   // channel ch (0..63) of conv-output gradient `layer`: waves with mb = ch / 32 hold it in register 4 g + j of lane half kq, where
@@ -108,10 +116,10 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
       float t = 0.0f;
 #pragma unroll
       for (int w4 = 0; w4 < 4; ++w4) {
-        const float* p = bpart + ((2 * w4 + m) * 4 + 2 * q) * 16 + 4 * g + j;
+        const float* p = bpart + ((layer * 8 + 2 * w4 + m) * 4 + 2 * q) * 16 + 4 * g + j;
         t += p[0] + p[16];
       }
-      bsum[layer * 64 + ch] += t;
+      bsum[layer * 64 + ch] = t;
     }
   };
 
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) emit(gk[kSeedSlot[s]][nb], nb, wave_uniform(gs + (size_t)(NL - 1) * ba.stride_g_layer));
-      bias_rows(gk[kSeedSlot[s]][0], gk[kSeedSlot[s]][1]);
+      bias_rows(gk[kSeedSlot[s]][0], gk[kSeedSlot[s]][1], NL - 1);
       for (int e = 0; e < NL; ++e) {       // executed layer e = conv NL-1-e backwards
         const int l = NL - 1 - e;
         const bool has_mask = e < NL - 1;
@@ -176,7 +184,6 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
           __builtin_amdgcn_s_barrier();
           if (u + 2 < U) issue((int)((u + 2) % UE), (r + 2) % 3);
           if (r == 0) {
-            bias_fold(l);                    // the row sums parked before this barrier belong to the gradient w.r.t. conv l's output
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
           }
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
           }
           emit(acc, nb, wave_uniform(gs + (size_t)(l - 1) * ba.stride_g_layer));
         }
-        bias_rows(acc0, acc1);
+        bias_rows(acc0, acc1, l - 1);
       }
       // ---- acc = gx_s = J_f(x_s)^T gk_s: the reverse Runge-Kutta bookkeeping (targets of fixed_grid.hip, same expressions)
       const float third = 1.0f / 3.0f;
@@ -306,7 +313,9 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
 #pragma unroll
       for (int j = 0; j < 4; ++j) dst[(size_t)j * kPix] = G[nb][4 * g + j];
     }
-  __syncthreads();   // every chain folded its five row-sum sets (the last one at its last layer's first kernel row)
+  __syncthreads();
+  for (int l = 0; l < NL; ++l) bias_fold(l);
+  __syncthreads();
   for (int i = threadIdx.x; i < NL * 64; i += 512) ba.bias_part[(size_t)b * NL * 64 + i] = bsum[i];
 }
 
@@ -342,8 +351,8 @@ int launch_btraj_bf16_rk4(const odehip_convstack* f_dgrad, const float* grad_out
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)btraj_bf16_rk4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  // LDS: tile + ring + [NL][64] sums (the bias slot) + 2 KiB of row sums
-  hipLaunchKernelGGL(btraj_bf16_rk4_kernel, dim3(batch), dim3(512), kFusedLds + 8 * 4 * 16 * 4, stream, ba);
+  // LDS: tile + ring + [NL][64] sums (the bias slot) + 2 KiB of running row sums per layer
+  hipLaunchKernelGGL(btraj_bf16_rk4_kernel, dim3(batch), dim3(512), kFusedLds + ODEHIP_MAX_LAYERS * 8 * 4 * 16 * 4, stream, ba);
   ODEHIP_CHECK_HIP(hipGetLastError());
   DbPack db;
   memset(&db, 0, sizeof(db));

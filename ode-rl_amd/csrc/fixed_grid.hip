@@ -86,6 +86,20 @@ __global__ void fill_u64_kernel(unsigned long long* dst, PtrPack p, int n) {
   if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
 }
 
+// table[e] = {g0 + e*gs, a0 + e*as, scale 1}: the evaluations of one layer are evenly spaced in the workspace, so the table is
+// built by one tiny launch instead of being shipped 32 values at a time through kernel arguments
+__global__ void wgrad_table_kernel(WgradPair* table, int n_eval, const char* g0, unsigned long long gs, const char* a0,
+                                   unsigned long long as) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_eval) return;
+  WgradPair p;
+  p.g = (const float*)(g0 + (size_t)e * gs);
+  p.a = (const float*)(a0 + (size_t)e * as);
+  p.scale = 1.0f;
+  p.pad_[0] = p.pad_[1] = p.pad_[2] = 0.0f;
+  table[e] = p;
+}
+
 static int check_common(const odehip_convstack* f, int method, const double* t_host, int n_times, int batch, const char* who) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
@@ -352,26 +366,10 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
     float* slabs = L.p(ws, L.off_slab);
     float* db_scratch = L.p(ws, L.off_gy);   // the reduce kernel's bias output (zeros here: the sweep summed the bias gradients)
     for (int l = 0; l < NL; ++l) {
-      for (int o = 0; o < 4 * n_eval; o += 32) {
-        PtrPack pk;
-        const int m = 4 * n_eval - o < 32 ? 4 * n_eval - o : 32;
-        for (int i = 0; i < m; ++i) {
-          const int e = (o + i) / 4, field = (o + i) & 3;
-          unsigned long long v = 0;
-          if (field == 0) v = (unsigned long long)(uintptr_t)((char*)L.p(ws, L.off_gp) + ((size_t)e * (NH + 1) + l) * L.hid);
-          else if (field == 1)
-            v = (unsigned long long)(uintptr_t)(l > 0 ? (char*)L.p(ws, L.off_hid) + ((size_t)e * NH + (l - 1)) * L.hid
-                                                      : (char*)L.p(ws, L.off_xin) + (size_t)e * L.st);
-          else if (field == 2) {
-            const float one = 1.0f;
-            unsigned u32;
-            memcpy(&u32, &one, 4);
-            v = u32;
-          }
-          pk.v[i] = v;
-        }
-        hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
-      }
+      const char* g0 = (const char*)L.p(ws, L.off_gp) + (size_t)l * L.hid;
+      const char* a0 = l > 0 ? (const char*)L.p(ws, L.off_hid) + (size_t)(l - 1) * L.hid : (const char*)L.p(ws, L.off_xin);
+      hipLaunchKernelGGL(wgrad_table_kernel, dim3((n_eval + 255) / 256), dim3(256), 0, stream, table, n_eval, g0, (size_t)(NH + 1) * L.hid,
+                         a0, l > 0 ? (size_t)NH * L.hid : L.st);
       rc = launch_wgrad_q4h(table, n_eval, batch, kEsplit, slabs, grad_w[l], db_scratch, stream);
       if (rc != ODEHIP_OK) return rc;
     }

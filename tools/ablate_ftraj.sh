@@ -3,20 +3,20 @@
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 AB=$ROOT/gpurun_ab/abl
-VARIANTS="base no_mfma no_rewrite no_rowbar no_xc no_epi"
+VARIANTS="${VARIANTS:-base no_bias no_gstore}"
 case "${1:-}" in
 build)
   for v in $VARIANTS; do
     d=$AB/$v; rm -rf "$d"; mkdir -p "$d/ode-rl_amd/csrc" "$d/include"
     cp "$ROOT"/ode-rl_amd/csrc/*.hip "$ROOT"/ode-rl_amd/csrc/*.h "$ROOT"/ode-rl_amd/csrc/Makefile "$d/ode-rl_amd/csrc/"
     cp "$ROOT"/include/*.h "$d/include/"
-    make -s -C "$d/ode-rl_amd/csrc" -j8 OUT_DIR="$d/lib" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -mllvm -amdgpu-kernarg-preload-count=8 -DFTRAJ_ABLATE_$v" >/dev/null 2>&1 || { echo "$v failed"; exit 1; }
+    make -s -C "$d/ode-rl_amd/csrc" -j8 OUT_DIR="$d/lib" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -mllvm -amdgpu-kernarg-preload-count=8 -DFTRAJ_ABLATE_$v -DBTRAJ_ABLATE_$v" >/dev/null 2>&1 || { echo "$v failed"; exit 1; }
     rm -rf "$d/ode-rl_amd/csrc/build"; echo built $v
   done ;;
 run)
   cd "$ROOT"
   for v in $VARIANTS; do
-    ODEHIP_LIB=$AB/$v/lib/libodecgru_hip.so python bench.py --dtype bf16 --batch ${2:-128} --frames 40 --steps 20 --no-cpu-baseline --no-config0 --no-train-leg 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['median_ms_per_step'],3), 'ms;', round(d['median_ms_per_step']*1e3/156,2), 'us per f')"
+    ODEHIP_LIB=$AB/$v/lib/libodecgru_hip.so python bench.py --dtype bf16 --batch ${2:-128} --frames 40 --steps 10 --no-cpu-baseline --no-config0 ${3:-} 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['median_ms_per_step'],3), 'ms;', round(d['median_ms_per_step']*1e3/156,2), 'us per f; train leg', d['train'] and round(d['train']['median_ms_per_step'],3))"
   done ;;
 esac
