@@ -170,7 +170,11 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
         if (has_mask) {                      // mask of the ReLU that fed conv l = saved hidden activation l-1, prefetched now
           const char* mk = wave_uniform(hs + (size_t)(l - 1) * ba.stride_h_layer);
 #pragma unroll
+#ifdef BTRAJ_ABLATE_no_mask
+          for (int i = 0; i < 8; ++i) mreg[i] = u32x2b{0x3f803f80u, 0x3f803f80u};
+#else
           for (int i = 0; i < 8; ++i) mreg[i] = gload8_untracked(mk + (q4h_off + (unsigned)((i & 3) * 2 * kPix * 8 + (i >> 2) * 32 * 8)));
+#endif
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r, ++u) {
@@ -251,10 +255,10 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float g = G[nb][i];
-            float o3 = gx[i] * (0.f + 1.f * h); o3 += g * (0.f + 0.375f * h);
-            float o2 = gx[i] * (0.f + -1.f * h); o2 += g * (0.f + 0.375f * h);
-            float o1 = gx[i] * (0.f + 1.f * h); o1 += g * (0.f + 0.125f * h);
-            float oy = gx[i] * (1.f + 0.f * h); oy += g * (1.f + 0.f * h);
+            const float o3 = __builtin_fmaf(g, 0.f + 0.375f * h, gx[i] * (0.f + 1.f * h));
+            const float o2 = __builtin_fmaf(g, 0.f + 0.375f * h, gx[i] * (0.f + -1.f * h));
+            const float o1 = __builtin_fmaf(g, 0.f + 0.125f * h, gx[i] * (0.f + 1.f * h));
+            const float oy = __builtin_fmaf(g, 1.f + 0.f * h, gx[i] * (1.f + 0.f * h));
             gk[2][nb][i] = o3; gk[1][nb][i] = o2; gk[0][nb][i] = o1; G[nb][i] = oy;
           }
         }
@@ -265,9 +269,9 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
           const f32x16& gx = nb ? acc1 : acc0;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            float oy = gx[i] * (1.f + 0.f * h); oy += G[nb][i] * (1.f + 0.f * h);
-            float o2 = gx[i] * (0.f + 1.f * h); o2 += gk[1][nb][i] * (1.f + 0.f * h);
-            float o1 = gx[i] * (0.f + -third * h); o1 += gk[0][nb][i] * (1.f + 0.f * h);
+            const float oy = __builtin_fmaf(G[nb][i], 1.f + 0.f * h, gx[i] * (1.f + 0.f * h));
+            const float o2 = __builtin_fmaf(gk[1][nb][i], 1.f + 0.f * h, gx[i] * (0.f + 1.f * h));
+            const float o1 = __builtin_fmaf(gk[0][nb][i], 1.f + 0.f * h, gx[i] * (0.f + -third * h));
             G[nb][i] = oy; gk[1][nb][i] = o2; gk[0][nb][i] = o1;
           }
         }
@@ -278,8 +282,8 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
           const f32x16& gx = nb ? acc1 : acc0;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            float oy = gx[i] * (1.f + 0.f * h); oy += G[nb][i] * (1.f + 0.f * h);
-            float o1 = gx[i] * (0.f + third * h); o1 += gk[0][nb][i] * (1.f + 0.f * h);
+            const float oy = __builtin_fmaf(G[nb][i], 1.f + 0.f * h, gx[i] * (1.f + 0.f * h));
+            const float o1 = __builtin_fmaf(gk[0][nb][i], 1.f + 0.f * h, gx[i] * (0.f + third * h));
             G[nb][i] = oy; gk[0][nb][i] = o1;
           }
         }
@@ -287,7 +291,11 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
         // stage 1 closes the interval: g(y_n) = gy + gx1 + grad_out[n]  (the next interval's seed is formed from it at its stage 4)
         // and the seed of interval n-1's stage 4, (h_{n-1}/8) g(y_n), as the per-launch path forms it: term by term
         f32x16 go[2];
+#ifdef BTRAJ_ABLATE_no_go
+        go[0] = G[1]; go[1] = G[0];
+#else
         load_go(n, go);
+#endif
         const float hb = n > 0 ? ba.hdev[n - 1] : 0.0f;
         const float cs = 0.f + 0.125f * hb;
 #pragma unroll
@@ -295,8 +303,8 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
           const f32x16& gx = nb ? acc1 : acc0;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            float o = gx[i] * (1.f + 0.f * hb); o += G[nb][i] * (1.f + 0.f * hb); o += go[nb][i] * (1.f + 0.f * hb);
-            float sd = gx[i] * cs; sd += G[nb][i] * cs; sd += go[nb][i] * cs;
+            const float o = __builtin_fmaf(go[nb][i], 1.f + 0.f * hb, __builtin_fmaf(G[nb][i], 1.f + 0.f * hb, gx[i] * (1.f + 0.f * hb)));
+            const float sd = __builtin_fmaf(go[nb][i], cs, __builtin_fmaf(G[nb][i], cs, gx[i] * cs));
             G[nb][i] = o;
             gk[0][nb][i] = sd;
           }

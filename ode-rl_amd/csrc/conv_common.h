@@ -26,6 +26,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 
+// o + a * c with ONE rounding per element, stated explicitly: the reverse Runge-Kutta bookkeeping exists in several kernels
+// (these epilogues and the register-resident sweep of btraj_bf16.hip) whose results are compared bit for bit -- left to the
+// compiler, `o += a * c` is contracted into an fma in one kernel and not in another
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float c, f32x4 o) {
+  return f32x4{__builtin_fmaf(a.x, c, o.x), __builtin_fmaf(a.y, c, o.y), __builtin_fmaf(a.z, c, o.z), __builtin_fmaf(a.w, c, o.w)};
+}
+
 // ---- per-(channel quad Q, pixel P) epilogue: plain / ReLU store, Runge-Kutta stage combine (+ adaptive error
 // partial), ReLU-mask backward, reverse-sweep targets.  `v` is the conv output (bias included) of 4 channels.
 // nchw_override: persistent trajectory kernel only -- where this layer's NCHW result frame goes (its table cannot hold the
@@ -56,8 +63,8 @@ __device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P
     for (int t = 0; t < w.n_targets; ++t) {
       const BwdTarget& T = w.tgt[t];
       f32x4 o = v * (T.g_c + T.g_h * hb);
-      if (T.srcA) o += *(const f32x4*)(T.srcA + off) * (T.a_c + T.a_h * hb);
-      if (T.srcB) o += *(const f32x4*)(T.srcB + off) * (T.b_c + T.b_h * hb);
+      if (T.srcA) o = fma4(*(const f32x4*)(T.srcA + off), T.a_c + T.a_h * hb, o);
+      if (T.srcB) o = fma4(*(const f32x4*)(T.srcB + off), T.b_c + T.b_h * hb, o);
       *(f32x4*)(T.out + off) = o;
     }
     return;
@@ -201,8 +208,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
       for (int t = 0; t < w.n_targets; ++t) {
         const BwdTarget& T = w.tgt[t];
         f32x4 o = gx * (T.g_c + T.g_h * hb);
-        if (T.srcA) o += *(const f32x4*)(T.srcA + off) * (T.a_c + T.a_h * hb);
-        if (T.srcB) o += *(const f32x4*)(T.srcB + off) * (T.b_c + T.b_h * hb);
+        if (T.srcA) o = fma4(*(const f32x4*)(T.srcA + off), T.a_c + T.a_h * hb, o);
+        if (T.srcB) o = fma4(*(const f32x4*)(T.srcB + off), T.b_c + T.b_h * hb, o);
         *(f32x4*)(T.out + off) = o;
       }
     }

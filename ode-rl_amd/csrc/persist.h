@@ -38,6 +38,7 @@ class PersistScope {
   bool active_ = false;
   bool small_ = false;
   bool launched_ = false;
+  const unsigned* abort_word_ = nullptr;
 };
 
 // Whole-trajectory launches that need no cross-workgroup hand-off (bf16: one workgroup per sample) obey the same on/off switch

@@ -82,14 +82,15 @@ static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t s
 
 constexpr int kGuardRegions = 24;
 struct GuardArgs {
-  const unsigned* host_err;
+  const unsigned* abort_word;   // DEVICE word of the launch's flag area: 1 if a wait of that launch gave up (the mapped host word
+                                // says the same, but a read over PCIe by every thread costs tens of microseconds)
   int n;
   float* p[kGuardRegions];
   unsigned long long floats[kGuardRegions];
 };
 
 __global__ void persist_guard_kernel(const GuardArgs a) {
-  if (__hip_atomic_load(a.host_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) return;
+  if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   for (int r = 0; r < a.n; ++r)
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.floats[r]; i += (unsigned long long)gridDim.x * blockDim.x)
       a.p[r][i] = __builtin_nanf("");
@@ -121,11 +122,11 @@ unsigned persist_error(bool clear) {
 PersistScope::PersistScope() : lock_(g_persist.mu, std::defer_lock) {}
 
 int PersistScope::guard(float* const* regions, const size_t* floats, int n, hipStream_t stream) {
-  if (!launched_ || !g_persist.host_err_dev) return ODEHIP_OK;
+  if (!launched_ || !abort_word_) return ODEHIP_OK;
   for (int base = 0; base < n; base += kGuardRegions) {
     GuardArgs a;
     memset(&a, 0, sizeof(a));
-    a.host_err = g_persist.host_err_dev;
+    a.abort_word = abort_word_;
     a.n = n - base < kGuardRegions ? n - base : kGuardRegions;
     for (int i = 0; i < a.n; ++i) {
       a.p[i] = regions[base + i];
@@ -210,8 +211,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
                                                   P.host_err_dev, kPersistGrid, stream);
         if (rcs == ODEHIP_OK) {
           ++P.launches;
-          launched_ = true;
-          return rcs;
+          return rcs;   // (small launches: epoch-tagged flag area, no guard -- their callers synchronise and check the host word)
         }
         P.enabled = 0;
         (void)hipGetLastError();
@@ -244,6 +244,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
       if (rc == ODEHIP_OK) {
         ++g_persist.launches;
         launched_ = true;
+        abort_word_ = sync + (size_t)batch * kPersistDoneStride + kPersistGrid;   // xcc_of[grid]: zeroed above, epoch 0 => tag 1
         return rc;
       }
       g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on

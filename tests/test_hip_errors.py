@@ -59,7 +59,7 @@ def test_c_abi_rejects_small_workspaces_and_bad_arguments(cuda):
     t = (ctypes.c_double * n)(0.0, 0.5, 1.0)
     need = lib.odehip_odeint_workspace_bytes(ctypes.byref(desc), b, n, 2, 1)
     ws = torch.empty(need // 2, dtype=torch.uint8, device=cuda)
-    rc = lib.odehip_odeint_fixed(ctypes.byref(desc), 2, z0.data_ptr(), t, n, b, out.data_ptr(), 1, 0, ws.data_ptr(), ws.numel(), None)
+    rc = lib.odehip_odeint_fixed(ctypes.byref(desc), 2, z0.data_ptr(), t, n, b, out.data_ptr(), 1, 0, ws.data_ptr(), ws.numel(), ctypes.byref(ctypes.c_int(0)), None)
     assert rc == -1 and b"workspace too small" in lib.odehip_last_error()
     # backward through dopri5 with a step log that does not tile [t0, t1]
     gw = (ctypes.c_void_p * 5)(*[torch.empty_like(c.weight).data_ptr() for c in stack.convs])
