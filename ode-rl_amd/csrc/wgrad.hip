@@ -547,47 +547,105 @@ __global__ __launch_bounds__(256, 1) void wgrad64_q4h_kernel(const WgradPair* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // per-lane bases of the transposed reads: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 of the group's 16
+  // Tile layout: 192 B per pixel slot (conflict-free transposed reads), and inside a slot the four 16-channel groups are XOR-swizzled
+  // with f(slot) = (slot >> 2) & 3.  Why: the tiles are FILLED from Q4h ([quad][pixel], 8 B), and with one pixel per thread the 64
+  // lanes of a ds_write_b64 are 192 B apart = only 4 distinct bank groups -- a 16-way conflict that cost 40 % of the kernel
+  // (ablation: 534 -> 316 us without the fill).  Filling 16 consecutive pixels x 4 quads per wave keeps the global loads in 128-B
+  // runs, and the swizzle spreads pixels p, p+4, p+8, p+12 (same bank group at a 192-B stride) over the four channel groups:
+  // 2 accesses per bank, the minimum for 512 B.
   const int grp = lane >> 4, l16 = lane & 15, q = l16 >> 2, p4 = l16 & 3, h = lane >> 5;
-  const char* gbase = gt + (8 * h + q) * kWS + (mb * 32 + 16 * (grp & 1) + 4 * p4) * 2;
-  const char* abase = at + (8 * h + q) * kWS + (nb * 32 + 16 * (grp & 1) + 4 * p4) * 2;  // + (row*18 + col offset) * kWS per tap
+  auto chan_off = [&](int group16, int slot) { return (4 * (group16 ^ ((slot >> 2) & 3)) + p4) * 8; };   // byte offset of this lane's quad
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4w;
+  auto tr_two = [&](const char* p0, const char* p1) {   // two transposed reads (pixels 8h+q and 8h+q+4 of a 16-pixel run)
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w*)p1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8w, v);
+  };
+  // G: slot = pixel; row y starts at slot 16 y, so f only depends on the lane: (2h) & 3 for the first read, (2h + 1) & 3 for the second
+  const int gs0 = 8 * h + q;
+  const char* gbase0 = gt + gs0 * kWS + chan_off(2 * mb + (grp & 1), gs0);
+  const char* gbase1 = gt + (gs0 + 4) * kWS + chan_off(2 * mb + (grp & 1), gs0 + 4);
 
   // operands are ALREADY bf16 ("Q4h": [sample][quad][pixel] x 4 bf16 = 8 bytes; written by ftraj_bf16_kernel<RK4, SAVE> and
-  // btraj_bf16_rk4_kernel): half the HBM bytes of the fp32 kernel above -- which is what bounds it -- and no conversion
-  u32x2w gv[16], av[16];
-  auto prefetch = [&](int e) {
-    const WgradPair pr = table[e];
-    const u32x2w* g = (const u32x2w*)pr.g + ((size_t)b * g_quads + g_quad0) * kPix + tid;
-    const u32x2w* a = (const u32x2w*)pr.a + ((size_t)b * a_quads + a_quad0) * kPix + tid;
+  // btraj_bf16_rk4_kernel): half the HBM bytes of the fp32 kernel above and no conversion.  Thread (wave w, lane) moves quad
+  // 4 w + (lane >> 4) of pixel 16 j + (lane & 15) in iteration j.
+  const int fq = 4 * wave + (lane >> 4), fx = lane & 15;
+  u32x2w gvA[16], avA[16];
+  auto prefetch = [&](const WgradPair& pr, u32x2w (&gv)[16], u32x2w (&av)[16]) {
+    const u32x2w* g = (const u32x2w*)pr.g + ((size_t)b * g_quads + g_quad0 + fq) * kPix + fx;
+    const u32x2w* a = (const u32x2w*)pr.a + ((size_t)b * a_quads + a_quad0 + fq) * kPix + fx;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      gv[i] = g[i * 256];
-      av[i] = a[i * 256];
+    for (int j = 0; j < 16; ++j) {
+      gv[j] = g[j * 16];
+      av[j] = a[j * 16];
     }
   };
-  if (es < n_eval) prefetch(es);
+  auto fill = [&](const u32x2w (&gv)[16], const u32x2w (&av)[16]) {
+    const int gq = (fq ^ (4 * ((fx >> 2) & 3))) * 8;       // G: slot = 16 j + fx, f = (fx >> 2) & 3 for every j
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      *(u32x2w*)(gt + (j * 16 + fx) * kWS + gq) = gv[j];
+      const int s = (j + 1) * 18 + fx + 1;                 // A: image pixel (j, fx) sits in tile slot (j + 1, fx + 1)
+      *(u32x2w*)(at + s * kWS + (fq ^ (4 * ((s >> 2) & 3))) * 8) = av[j];
+    }
+  };
+  auto multiply = [&]() {
+  // The three taps of a kernel row are the SAME image row shifted by one pixel along K (= the pixel index of the MFMA), and tile
+  // row r serves output rows r, r-1, r-2 (dy = 0, 1, 2): every tile row is read ONCE (2 transposed reads) -- K element j of lane
+  // half h = tile column 1 + 8h + j -- and the dx = 0 / 2 operands are derived in registers: a 16-bit funnel shift of the lane's 8
+  // values, the value that crosses the half boundary comes from lane ^ 32, the one that crosses the row's end is the zero
+  // padding.  18 x 2 transposed reads + 18 lane exchanges per evaluation instead of 16 x 18 x 2 reads.
+  // Same operands and the same accumulation order per tap (y ascending) as wgrad64_bf16_kernel: bit-identical results.
+  typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+  bf16x8w gprev[2];   // G fragments of output rows r-1, r-2
+#pragma unroll 6
+  for (int r = 0; r < 18; ++r) {
+    const int as0 = r * 18 + 1 + 8 * h + q;
+    const bf16x8w ac = tr_two(at + as0 * kWS + chan_off(2 * nb + (grp & 1), as0), at + (as0 + 4) * kWS + chan_off(2 * nb + (grp & 1), as0 + 4));
+    const u32x4w d = __builtin_bit_cast(u32x4w, ac);
+    const unsigned recv = (unsigned)__shfl_xor((int)(h ? d[0] : d[3]), 32, 64);   // h = 0 sends its element 7, h = 1 its element 0
+    const unsigned xr = h ? 0u : recv;   // low 16 bits: element 0 of the upper half = the pixel right of this lane's eight
+    const unsigned xl = h ? recv : 0u;   // high 16 bits: element 7 of the lower half = the pixel left of this lane's eight
+    const u32x4w dl = {__builtin_amdgcn_alignbit(d[0], xl, 16), __builtin_amdgcn_alignbit(d[1], d[0], 16),
+                       __builtin_amdgcn_alignbit(d[2], d[1], 16), __builtin_amdgcn_alignbit(d[3], d[2], 16)};   // tile column k + 0
+    const u32x4w dr = {__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                       __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(xr, d[3], 16)};     // tile column k + 2
+    const bf16x8w al = __builtin_bit_cast(bf16x8w, dl), ar = __builtin_bit_cast(bf16x8w, dr);
+    bf16x8w gcur = ac;
+    if (r < 16) gcur = tr_two(gbase0 + r * 16 * kWS, gbase1 + r * 16 * kWS);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {       // output row y = r - dy
+      const int y = r - dy;
+      if (y < 0 || y > 15) continue;
+      const bf16x8w gf = dy == 0 ? gcur : gprev[dy - 1];
+      acc[3 * dy] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, al, acc[3 * dy], 0, 0, 0);
+      acc[3 * dy + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ac, acc[3 * dy + 1], 0, 0, 0);
+      acc[3 * dy + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, ar, acc[3 * dy + 2], 0, 0, 0);
+    }
+    gprev[1] = gprev[0];
+    gprev[0] = gcur;
+  }
+  };
+  // The table entry of an evaluation is fetched one evaluation BEFORE its operands are requested: read where it is needed it puts a
+  // dependent trip to memory (entry -> addresses -> operands) in front of every operand load
+  WgradPair pr_next;
+  pr_next.g = pr_next.a = nullptr;
+  if (es < n_eval) {
+    prefetch(table[es], gvA, avA);
+    if (es + esplit < n_eval) pr_next = table[es + esplit];
+  }
   for (int e = es; e < n_eval; e += esplit) {
     __syncthreads();  // every wave is done with the previous evaluation's tiles
-    {
-      const int prow = tid >> 4, pcol = tid & 15;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {   // quad i of pixel tid
-        *(u32x2w*)(gt + tid * kWS + i * 8) = gv[i];
-        *(u32x2w*)(at + ((prow + 1) * 18 + pcol + 1) * kWS + i * 8) = av[i];
-      }
-    }
+    fill(gvA, avA);
     __syncthreads();
-    if (e + esplit < n_eval) prefetch(e + esplit);  // in flight while this evaluation is multiplied
-#pragma unroll 2
-    for (int y = 0; y < 16; ++y) {
-      const bf16x8w gf = tr_pair(gbase + y * 16 * kWS);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3, dx = t % 3;  // tile coordinates: row y + dy, column x + dx (border included)
-        const bf16x8w af = tr_pair(abase + ((y + dy) * 18 + dx) * kWS);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, af, acc[t], 0, 0, 0);
-      }
+    if (e + esplit < n_eval) {
+      prefetch(pr_next, gvA, avA);                                   // in flight while this evaluation is multiplied
+      if (e + 2 * esplit < n_eval) pr_next = table[e + 2 * esplit];
     }
+    __builtin_amdgcn_sched_barrier(0);                               // the loads are issued before the multiply, not sunk below it
+    multiply();
   }
 
   float* slab = slabs + (size_t)(b * esplit + es) * (64 * 64 * 9 + 64);
