@@ -34,13 +34,15 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); the bf16 co
 
 
 def profiled_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate --pmc passes,
-    FETCH_SIZE doubled per the gfx950 correction); None if the summary is absent.  Not measured live."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")) as fh:
-            return float(json.load(fh)["notes"]["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (separate --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction); None if no summary is present.  Not measured live."""
+    for tag in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")) as fh:
+                return float(json.load(fh)["notes"]["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def parse():
@@ -378,6 +380,14 @@ def main():
             # (339.7 MFLOP per latent frame for A, T=10); duration = the timed region / steps (the copy of
             # z0, the layout kernel and two tiny fills ride along: < 2 %)
             kernel, launches, flop_per_launch = "wino_persist_kernel", a.steps, F_f * nfe_per_step
+        elif fused_bf16 and persistent == a.steps and a.method != "dopri5":
+            # bf16, 64-channel stack: the whole trajectory is ONE launch of ftraj_bf16_kernel (one workgroup per sample)
+            kernel, launches, flop_per_launch = "ftraj_bf16_kernel", a.steps, F_f * nfe_per_step
+        elif a.method == "dopri5" and persistent > 0 and a.dtype == "f32":
+            # dopri5 forward: every attempted step (6 evaluations of f) is one launch of wino_persist_kernel; the two evaluations
+            # of the initial-step search run as per-layer launches and are left out of this entry
+            kernel, launches, flop_per_launch = "wino_persist_kernel (one launch per attempted step)", persistent, 6 * F_f
+            note = "dev time of the whole region / persistent launches; the 2 evaluations of the initial-step search ride along"
         elif fused_bf16:
             kernel, launches, flop_per_launch = "fstack_bf16_kernel", nfe_per_step * a.steps, F_f      # one launch per evaluation of f
         else:
