@@ -172,6 +172,7 @@ static bool bf16_trajectory_ok(const odehip_convstack* f, int method) {
     if (f->channels[l] != 64) return false;
   return method == ODEHIP_EULER || method == ODEHIP_MIDPOINT || method == ODEHIP_RK4;
 }
+constexpr int kMaxWgradEvals = 32 * 64;   // evaluations one weight-gradient table holds
 
 extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const float* z0_nchw, const double* t_host,
                                    int n_times, int batch, float* out_nchw, int save_for_backward, int negate,
@@ -205,7 +206,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   // bf16 compute, 64-channel stack: the whole trajectory as ONE launch with one workgroup per sample -- state and stage derivatives
   // in registers, activations in LDS (fstack_bf16.hip: ftraj_bf16_kernel).  A training forward (rk4) also saves every stage input
   // and hidden activation as bf16 for the one-launch reverse sweep (btraj_bf16.hip): saved format 1.
-  if (bf16_trajectory_ok(f, method) && (!save_for_backward || method == ODEHIP_RK4)) {
+  if (bf16_trajectory_ok(f, method) && (!save_for_backward || (method == ODEHIP_RK4 && (n_times - 1) * 4 <= kMaxWgradEvals))) {
     if (save_for_backward) {
       rc = launch_ftraj_bf16_saving(f, z0_nchw, out_nchw, hdev, n_times, batch, L.p(ws, L.off_xin), L.st, L.p(ws, L.off_hid),
                                     (size_t)L.NH * L.hid, L.hid, stream);

@@ -276,3 +276,41 @@ def test_whole_trajectory_training_matches_per_evaluation_launches(cuda, bf16_mo
         assert record(f"bf16.train.gb{l}.B{batch}", rel_l2(a, b)) <= 1e-5
     for a, b in zip([again[0], again[1]] + again[2] + again[3], [got[0], got[1]] + got[2] + got[3]):
         assert torch.equal(a, b)     # deterministic
+
+
+@pytest.mark.parametrize("n_layers,batch,n_times", [(1, 2, 2), (5, 3, 3), (3, 1, 2)])
+def test_whole_trajectory_launches_with_other_stack_depths(cuda, bf16_mode, n_layers, batch, n_times):
+    """Edge cases of the one-launch bf16 paths: stacks of 3 and 7 convs (create_convnet n_layers 1 / 5), a single interval, a
+    single sample -- forward bit-identical to per-evaluation launches, gradients within the bounds of the test above."""
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    torch.manual_seed(20 + n_layers)
+    f = ode_rl_amd.ODEFunc(64, 64, n_layers, 64, False, "relu", final_act=False).to(cuda)
+    assert sum(isinstance(m, torch.nn.Conv2d) for m in f.gradient_net) == n_layers + 2
+    g = torch.Generator().manual_seed(7 * n_layers + batch)
+    z0 = (torch.randn(batch, 64, 16, 16, generator=g) * 0.5).to(cuda)
+    t = torch.arange(n_times, 2 * n_times, dtype=torch.float64) / (2 * n_times)
+    gout = torch.randn(n_times, batch, 64, 16, 16, generator=g).to(cuda)
+
+    def run(train):
+        if not train:
+            with torch.no_grad():
+                return [ode_rl_amd.odeint(f, z0, t, method="rk4")]
+        f.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        out = ode_rl_amd.odeint(f, z, t, method="rk4")
+        out.backward(gout)
+        return [out.detach().clone(), z.grad.clone()] + [p.grad.clone() for p in f.parameters()]
+
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        ref_f, ref_t = run(False), run(True)
+        lib.odehip_set_persistent_trajectory(1)
+        n0 = lib.odehip_persistent_trajectory_launches()
+        got_f, got_t = run(False), run(True)
+        assert lib.odehip_persistent_trajectory_launches() == n0 + 2
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
+    assert torch.equal(got_f[0], ref_f[0]) and torch.equal(got_t[0], ref_t[0])
+    for a, b in zip(got_t[1:], ref_t[1:]):
+        assert rel_l2(a, b) <= 1e-5
