@@ -19,7 +19,11 @@
  *         64 KiB host mailbox that the library allocates on first use (hipHostMalloc);
  *       * odehip_odeint_adjoint_dopri5_backward reads one 8-byte verdict per attempted step from pinned host memory it
  *         allocates on first use, and odehip_odeint_dopri5_backward synchronises once per layer for its wgrad table;
- *       * the "small" persistent launches (ODEHIP_PERSISTENT_SMALL=1 only) own a flag area in device memory.
+ *       * the "small" persistent launches (ODEHIP_PERSISTENT_SMALL=1 only) own a flag area in device memory;
+ *       * odehip_odeint_fixed_backward with saved_format 1 (bf16 whole-trajectory path) runs its weight-gradient launches on a
+ *         library-owned side stream, ordered against the caller's stream by events in both directions (the caller's stream
+ *         continues only when the side stream is done with the workspace and the gradients); ODEHIP_BF16_OVERLAP=0 keeps
+ *         everything on the caller's stream.
  *   - library state (table cache, mailbox, error word, flag areas) is process-global and serves ONE stream at a time:
  *     the library assumes one process per GPU driving it from a single stream (the Python binding passes torch's
  *     current stream); concurrent calls from several streams or threads are not supported.

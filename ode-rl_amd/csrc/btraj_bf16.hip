@@ -25,6 +25,12 @@ struct BtrajArgs {
   float* bias_part;                      // out: [B][NL][64] per-sample bias-gradient sums (fp32)
   unsigned long long stride_h_eval, stride_h_layer, stride_g_eval, stride_g_layer;
   int n_layers, n_steps, batch;
+  // this launch sweeps the intervals n_hi-1 .. n_lo.  n_hi == n_steps: the state starts from grad_out[T-1]; else it is read from
+  // state_g (dL/dy at t[n_hi], grad_out included) and state_seed (the seed of interval n_hi-1's stage 4), both (B,64,16,16) fp32, as
+  // the launch of the later intervals left them.  n_lo == 0: grad_z0 is written; else the state goes to state_g / state_seed.
+  int n_lo, n_hi;
+  float* state_g;
+  float* state_seed;
 };
 
 typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
   const int NL = ba.n_layers, UE = NL * 3, S = 4;
-  const long long U = (long long)ba.n_steps * S * UE;
+  const long long U = (long long)(ba.n_hi - ba.n_lo) * S * UE;
 
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(ba.w_fused, (unsigned)(UE * kFUnit));
   const int vw = lane * 16;
@@ -135,19 +141,43 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
         for (int j = 0; j < 4; ++j) dst[nb][4 * g + j] = src[(size_t)j * kPix];
       }
   };
-  load_go(ba.n_steps, G);
-  {  // seed of the last interval: (0 + wlast * h) * grad_out[T-1]   (fixed_grid.hip: scale_kernel)
+  auto load_state = [&](const float* base, f32x16 (&dst)[2]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* src = base + ((size_t)b * 64 + mb * 32 + 8 * g + 4 * kq) * kPix + (nb ? P1 : P0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[nb][4 * g + j] = src[(size_t)j * kPix];
+      }
+  };
+  auto store_state = [&](float* base, const f32x16 (&src)[2]) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float* dst = base + ((size_t)b * 64 + mb * 32 + 8 * g + 4 * kq) * kPix + (nb ? P1 : P0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(size_t)j * kPix] = src[nb][4 * g + j];
+      }
+  };
+  if (ba.n_hi == ba.n_steps) {
+    load_go(ba.n_steps, G);
+    // seed of the last interval: (0 + wlast * h) * grad_out[T-1]   (fixed_grid.hip: scale_kernel)
     const float c = 0.0f + 0.125f * ba.hdev[ba.n_steps - 1];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) gk[0][nb][i] = G[nb][i] * c;
+  } else {
+    load_state(ba.state_g, G);
+    load_state(ba.state_seed, gk[0]);
   }
 
   long long u = 0;
   f32x16 acc0, acc1;
   u32x2b mreg[8];
-  for (int n = ba.n_steps - 1; n >= 0; --n) {
+  for (int n = ba.n_hi - 1; n >= ba.n_lo; --n) {
     const float h = ba.hdev[n];
 #pragma unroll
     for (int s = 3; s >= 0; --s) {
@@ -312,48 +342,51 @@ __global__ __launch_bounds__(512, 1) void btraj_bf16_rk4_kernel(const BtrajArgs 
       }
     }
   }
-  // grad z0 (NCHW) and this sample's bias-gradient sums
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float* dst = ba.grad_z0_nchw + ((size_t)b * 64 + mb * 32 + 8 * g + 4 * kq) * kPix + (nb ? P1 : P0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dst[(size_t)j * kPix] = G[nb][4 * g + j];
-    }
+  // grad z0 (NCHW) -- or the state for the launch that sweeps the earlier intervals -- and this sample's bias-gradient sums
+  if (ba.n_lo == 0) {
+    store_state(ba.grad_z0_nchw, G);
+  } else {
+    store_state(ba.state_g, G);
+    store_state(ba.state_seed, gk[0]);
+  }
   __syncthreads();
   for (int l = 0; l < NL; ++l) bias_fold(l);
   __syncthreads();
   for (int i = threadIdx.x; i < NL * 64; i += 512) ba.bias_part[(size_t)b * NL * 64 + i] = bsum[i];
 }
 
-// db[l][ch] = sum over samples of bias_part[b][l][ch], in order
-__global__ __launch_bounds__(64) void bias_reduce_kernel(const float* __restrict__ part, int batch, int n_layers, float* const* __restrict__ db) {
-  const int l = blockIdx.x, ch = threadIdx.x;
-  float t = 0.0f;
-  for (int b = 0; b < batch; ++b) t += part[((size_t)b * n_layers + l) * 64 + ch];
-  db[l][ch] = t;
-}
-
+// db[l][ch] = sum over the parts (segments x samples) of bias_part[part][l][ch], in order
 struct DbPack {
   float* p[ODEHIP_MAX_LAYERS];
 };
-__global__ __launch_bounds__(64) void bias_reduce_pack_kernel(const float* __restrict__ part, int batch, int n_layers, DbPack db) {
+__global__ __launch_bounds__(64) void bias_reduce_pack_kernel(const float* __restrict__ part, int n_parts, int n_layers, DbPack db) {
   const int l = blockIdx.x, ch = threadIdx.x;
   float t = 0.0f;
-  for (int b = 0; b < batch; ++b) t += part[((size_t)b * n_layers + l) * 64 + ch];
+  for (int b = 0; b < n_parts; ++b) t += part[((size_t)b * n_layers + l) * 64 + ch];
   db.p[l][ch] = t;
 }
 
+int launch_bias_reduce(const float* bias_part, int n_parts, int n_layers, float* const* grad_b, hipStream_t stream) {
+  DbPack db;
+  memset(&db, 0, sizeof(db));
+  for (int l = 0; l < n_layers; ++l) db.p[l] = grad_b[l];
+  hipLaunchKernelGGL(bias_reduce_pack_kernel, dim3(n_layers), dim3(64), 0, stream, bias_part, n_parts, n_layers, db);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
 int launch_btraj_bf16_rk4(const odehip_convstack* f_dgrad, const float* grad_out_nchw, float* grad_z0_nchw, const float* hdev, int n_times,
-                          int batch, const void* save_h, size_t stride_h_eval, size_t stride_h_layer, void* save_g, size_t stride_g_eval,
-                          size_t stride_g_layer, float* bias_part, float* const* grad_b, hipStream_t stream) {
+                          int batch, int n_lo, int n_hi, float* state_g, float* state_seed, const void* save_h, size_t stride_h_eval,
+                          size_t stride_h_layer, void* save_g, size_t stride_g_eval, size_t stride_g_layer, float* bias_part,
+                          hipStream_t stream) {
   BtrajArgs ba;
   memset(&ba, 0, sizeof(ba));
   ba.grad_out_nchw = grad_out_nchw; ba.grad_z0_nchw = grad_z0_nchw; ba.hdev = hdev; ba.w_fused = f_dgrad->w_fused;
   ba.save_h = (const char*)save_h; ba.save_g = (char*)save_g; ba.bias_part = bias_part;
   ba.stride_h_eval = stride_h_eval; ba.stride_h_layer = stride_h_layer; ba.stride_g_eval = stride_g_eval; ba.stride_g_layer = stride_g_layer;
   ba.n_layers = f_dgrad->n_convs; ba.n_steps = n_times - 1; ba.batch = batch;
+  ba.n_lo = n_lo; ba.n_hi = n_hi; ba.state_g = state_g; ba.state_seed = state_seed;
+  ODEHIP_REQUIRE(0 <= n_lo && n_lo < n_hi && n_hi <= n_times - 1, "btraj_bf16: bad interval range [%d, %d)", n_lo, n_hi);
   static bool attr_set = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)btraj_bf16_rk4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -361,11 +394,6 @@ int launch_btraj_bf16_rk4(const odehip_convstack* f_dgrad, const float* grad_out
   }
   // LDS: tile + ring + [NL][64] sums (the bias slot) + 2 KiB of running row sums per layer
   hipLaunchKernelGGL(btraj_bf16_rk4_kernel, dim3(batch), dim3(512), kFusedLds + ODEHIP_MAX_LAYERS * 8 * 4 * 16 * 4, stream, ba);
-  ODEHIP_CHECK_HIP(hipGetLastError());
-  DbPack db;
-  memset(&db, 0, sizeof(db));
-  for (int l = 0; l < f_dgrad->n_convs; ++l) db.p[l] = grad_b[l];
-  hipLaunchKernelGGL(bias_reduce_pack_kernel, dim3(f_dgrad->n_convs), dim3(64), 0, stream, bias_part, batch, f_dgrad->n_convs, db);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

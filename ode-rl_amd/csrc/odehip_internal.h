@@ -159,14 +159,19 @@ struct WgradPair {
 // bf16 = true: operands rounded to bf16 (fp32 accumulation), for stacks running in bf16 compute mode
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                  int cin, hipStream_t stream, bool bf16 = false);
-int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db_scratch,
+int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, int accumulate,
                      hipStream_t stream);
 int launch_ftraj_bf16_saving(const odehip_convstack* f, const float* z0_nchw, float* out_nchw, const float* hdev, int n_times, int batch,
                              void* save_x, size_t stride_x, void* save_h, size_t stride_h_eval, size_t stride_h_layer,
                              hipStream_t stream);
+// reverse sweep over the intervals n_hi-1 .. n_lo (n_hi == n_times-1: starts from grad_out[T-1], else from state_g / state_seed as the
+// previous segment left them; n_lo == 0: writes grad_z0, else leaves its state in state_g / state_seed); bias_part: [B][NL][64]
 int launch_btraj_bf16_rk4(const odehip_convstack* f_dgrad, const float* grad_out_nchw, float* grad_z0_nchw, const float* hdev, int n_times,
-                          int batch, const void* save_h, size_t stride_h_eval, size_t stride_h_layer, void* save_g, size_t stride_g_eval,
-                          size_t stride_g_layer, float* bias_part, float* const* grad_b, hipStream_t stream);
+                          int batch, int n_lo, int n_hi, float* state_g, float* state_seed, const void* save_h, size_t stride_h_eval,
+                          size_t stride_h_layer, void* save_g, size_t stride_g_eval, size_t stride_g_layer, float* bias_part,
+                          hipStream_t stream);
+// grad_b[l][ch] = sum over segments and samples of bias_part[seg][b][l][ch], in order
+int launch_bias_reduce(const float* bias_part, int n_parts, int n_layers, float* const* grad_b, hipStream_t stream);
 int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
                       int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
                       hipStream_t stream);

@@ -816,8 +816,32 @@ int launch_wgrad_bf16(const WgradPair* table_dev, int n_eval, int batch, int esp
   return ODEHIP_OK;
 }
 
-// operands in Q4h (bf16); db is NOT written (db_scratch receives the zeros of the slabs): the caller sums the bias gradient itself
-int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db_scratch,
+// dw (+)= sum of the slabs' weight part, fixed order (the bias part of a Q4h slab is zero: the reverse sweep sums the bias gradients)
+__global__ __launch_bounds__(256) void wgrad_reduce_acc_kernel(const float* __restrict__ slabs, int n_slabs, int slab_floats,
+                                                               float* __restrict__ dw, int accumulate) {
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  if (i < 64 * 64 * 9) {
+    for (int k = g; k < n_slabs; k += 16) {
+      p0 += slabs[(size_t)k * slab_floats + i];
+      if (k + 4 < n_slabs) p1 += slabs[(size_t)(k + 4) * slab_floats + i];
+      if (k + 8 < n_slabs) p2 += slabs[(size_t)(k + 8) * slab_floats + i];
+      if (k + 12 < n_slabs) p3 += slabs[(size_t)(k + 12) * slab_floats + i];
+    }
+  }
+  part[g][o] = (p0 + p1) + (p2 + p3);
+  __syncthreads();
+  if (g == 0 && i < 64 * 64 * 9) {
+    const float s = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    dw[i] = accumulate ? dw[i] + s : s;   // a 64 x 64 layer: the slab's (co, ci, tap) order IS the OIHW order
+  }
+}
+
+// operands in Q4h (bf16), one 64 -> 64 layer; dw = (accumulate ? dw : 0) + sum over the table's evaluations.  The bias gradient is
+// NOT produced here (the reverse sweep sums it from the unrounded gradients).
+int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, int accumulate,
                      hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -826,7 +850,7 @@ int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int espl
   }
   const int sf = 64 * 64 * 9 + 64;
   hipLaunchKernelGGL(wgrad64_q4h_kernel, dim3(batch, esplit), dim3(256), kWgradBf16Lds, stream, table_dev, n_eval, esplit, slabs, 0, 16, 0, 16);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((sf + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, db_scratch, 64, 0, 0);
+  hipLaunchKernelGGL(wgrad_reduce_acc_kernel, dim3((64 * 64 * 9 + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sf, dw, accumulate);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
