@@ -1,9 +1,13 @@
 #!/bin/bash
-# Ablation builds of ftraj_bf16_kernel (timing only: results are wrong by construction).  `build` here, `run` on the GPU box.
+# Ablation builds of the one-launch bf16 kernels (timing only: results are wrong by construction).  `build` here, `run` on the GPU box.
+# Variants = macros BTRAJ_ABLATE_<v> in csrc/btraj_bf16.hip: no_bias (no bias-gradient sums), no_gstore (conv-output gradients not
+# stored), no_mask (saved masks not loaded), no_go (grad_out not loaded).  (The forward kernel's ablations -- row barriers 1.45 us,
+# tile rewrites 1.3 us, stage epilogue 0.6 us, activation-fragment latency 0.5 us per evaluation -- were taken with macros that
+# have since been removed from fstack_bf16.hip: DESIGN.md section 4.2c.)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 AB=$ROOT/gpurun_ab/abl
-VARIANTS="${VARIANTS:-base no_bias no_gstore}"
+VARIANTS="${VARIANTS:-base no_bias no_gstore no_mask no_go}"
 case "${1:-}" in
 build)
   for v in $VARIANTS; do
