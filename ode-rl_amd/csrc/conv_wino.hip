@@ -70,10 +70,14 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
-__device__ __forceinline__ void wait_done(const PersistHook& hk) {
+// The flag line of a sample: word (2 ct + rh) * 4 + consumer wave.  The input chunks 2 ct', 2 ct' + 1 of the next layer (32 channels)
+// are exactly what the two workgroups with ct = ct' wrote: their loads only have to wait for THOSE eight words --
+// (word & sel_mask) == sel_val; the default waits for all sixteen.
+__device__ __forceinline__ void wait_done(const PersistHook& hk, int sel_mask = 0, int sel_val = 0) {
   int n = 0;
   const int lane = threadIdx.x & 63;
-  while (!__all(lane >= 16 || __hip_atomic_load(hk.done + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
+  const bool mine = lane < 16 && (lane & sel_mask) == sel_val;
+  while (!__all(!mine || __hip_atomic_load(hk.done + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
     __builtin_amdgcn_s_sleep(1);
     if ((++n & 1023) == 0) {
       if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hk.abort_tag) break;
@@ -195,7 +199,10 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     if (PERSIST) {
       if (pw == 0) pstamp(hk, 0, lane);
       issue_u(0, 0);                   // weights do not depend on the partners: requested before the wait
-      if (!hk.first) wait_done(hk);    // the previous layer of this sample is complete in L2
+      // chunks 0 and 1 are the channels of co tile 0: only ITS two workgroups must be done before they are loaded; co tile 1's are
+      // waited for in front of chunk 2 (same-box A/B over 10 alternations: median 1.4152 -> 1.4076 ms per trajectory; a wait per
+      // chunk -- four polls per layer -- costs more than it saves: 1.53 ms)
+      if (!hk.first) wait_done(hk, 0x8, 0x0);
       if (pw == 0) pstamp(hk, 1, lane);
       issue_raw(0, 0);
       issue_raw(1, 1);
@@ -218,6 +225,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       if (!skip && !dbg_noprod && c + 1 < nchunk) {
         if (!dbg_nodma) issue_u(c + 1, (c + 1) & 1);      // U buffer last read by the MFMAs of chunk c-1
         if (c + 2 < nchunk) {
+          if (PERSIST && c == 0 && !hk.first) wait_done(hk, 0x8, 0x8);   // chunks 2 and 3: co tile 1's workgroups
           if (!dbg_nodma) issue_raw(c + 2, c & 1);        // raw buffer consumed by this wave's transform of chunk c
           wait_vmcnt<12>();                               // raw_{c+1} landed
         } else {
