@@ -507,7 +507,6 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
     if (skip && *(ConstI*)skip) return;
   }
   const int n_groups = nwg >> 2;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // A group walks TWO samples at a time, layer by layer in turn (when the batch gives it more than one): the hand-off latency of
   // one sample's layer (stores acknowledged -> flags seen -> next input tile loaded) is then covered by the other sample's layer.
   for (int b = group; b < pa.batch; b += 2 * n_groups) {

@@ -192,8 +192,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   float* pong = L.p(ws, L.off_pong);
   float* k[3] = {L.p(ws, L.off_k), L.p(ws, L.off_k + L.st), L.p(ws, L.off_k + 2 * L.st)};
 
-  ODEHIP_CHECK_HIP(hipMemcpyAsync(out_nchw, z0_nchw, st_b, hipMemcpyDeviceToDevice, stream));  // solution[0] = y0
-  rc = odehip_nchw_to_q4(z0_nchw, L.y(ws, 0), batch, L.C, stream);
+  rc = nchw_to_q4_and_copy(z0_nchw, L.y(ws, 0), out_nchw, batch, L.C, stream);  // solution[0] = y0, and y0 in the kernels' layout
   if (rc != ODEHIP_OK) return rc;
   if (n_times == 1) return ODEHIP_OK;
 

@@ -21,6 +21,28 @@ __global__ __launch_bounds__(256) void nchw_to_q4_kernel(const float* __restrict
   (void)quads;
 }
 
+// the same, and a verbatim NCHW copy of the source on the way (solution[0] = y0 of the solvers: one launch instead of a
+// device-to-device memcpy plus the layout kernel)
+__global__ __launch_bounds__(256) void nchw_to_q4_copy_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              float* __restrict__ copy, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = idx & 255;
+  const int bq = idx >> 8;
+  const size_t o = (size_t)bq * 4 * kPix + p;
+  const f32x4 v = {src[o], src[o + kPix], src[o + 2 * kPix], src[o + 3 * kPix]};
+  *(f32x4*)(dst + (size_t)idx * 4) = v;
+  copy[o] = v.x; copy[o + kPix] = v.y; copy[o + 2 * kPix] = v.z; copy[o + 3 * kPix] = v.w;
+}
+
+int nchw_to_q4_and_copy(const float* src, float* dst_q4, float* copy_nchw, int batch, int channels, hipStream_t stream) {
+  ODEHIP_REQUIRE(src && dst_q4 && copy_nchw && batch > 0 && channels > 0 && channels % 4 == 0, "nchw_to_q4_and_copy: bad arguments");
+  const int total = batch * (channels / 4) * kPix;
+  hipLaunchKernelGGL(nchw_to_q4_copy_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, src, dst_q4, copy_nchw, total);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
 __global__ __launch_bounds__(256) void q4_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                          int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;

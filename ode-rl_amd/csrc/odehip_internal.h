@@ -134,6 +134,8 @@ extern unsigned long long* g_debug_buf;
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 int check_stack(const odehip_convstack* f);
+// NCHW -> Q4 and, in the same launch, a verbatim NCHW copy (solution[0] = y0)
+int nchw_to_q4_and_copy(const float* src, float* dst_q4, float* copy_nchw, int batch, int channels, hipStream_t stream);
 int max_hidden(const odehip_convstack* f);
 int upload_floats(float* dst, const float* src, int n, hipStream_t stream);  // scalars travel as kernel arguments (async)
 // f(x) with the stage combine fused into the last conv; `hidden` (n_convs-1 buffers) keeps the ReLU outputs for a backward pass
