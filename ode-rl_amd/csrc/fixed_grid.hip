@@ -192,15 +192,20 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   float* pong = L.p(ws, L.off_pong);
   float* k[3] = {L.p(ws, L.off_k), L.p(ws, L.off_k + L.st), L.p(ws, L.off_k + 2 * L.st)};
 
-  rc = nchw_to_q4_and_copy(z0_nchw, L.y(ws, 0), out_nchw, batch, L.C, stream);  // solution[0] = y0, and y0 in the kernels' layout
-  if (rc != ODEHIP_OK) return rc;
-  if (n_times == 1) return ODEHIP_OK;
-
   // step sizes: dt = t1 - t0 in float64, rounded to fp32 when it meets the state (torchdiffeq semantics)
   float hbuf[4096];
   for (int i = 0; i + 1 < n_times; ++i) hbuf[i] = (float)(t_host[i + 1] - t_host[i]);
-  rc = upload_floats(hdev, hbuf, n_times - 1, stream);
+  // ONE prologue launch: solution[0] = y0, y0 in the kernels' layout, the step sizes on the device, the persistent launch's flags zeroed
+  const bool h_in_prologue = n_times - 1 <= 64;
+  unsigned* psync = (unsigned*)L.p(ws, L.off_psync);
+  rc = traj_prologue(z0_nchw, L.y(ws, 0), out_nchw, batch, L.C, hbuf, h_in_prologue ? n_times - 1 : 0, hdev, psync,
+                     (int)(persist_sync_bytes(batch) / 4), stream);
   if (rc != ODEHIP_OK) return rc;
+  if (n_times == 1) return ODEHIP_OK;
+  if (!h_in_prologue) {
+    rc = upload_floats(hdev, hbuf, n_times - 1, stream);
+    if (rc != ODEHIP_OK) return rc;
+  }
 
   // bf16 compute, 64-channel stack: the whole trajectory as ONE launch with one workgroup per sample -- state and stage derivatives
   // in registers, activations in LDS (fstack_bf16.hip: ftraj_bf16_kernel).  A training forward (rk4) also saves every stage input
@@ -295,7 +300,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   return ODEHIP_OK;
   };
   rc = enqueue_steps();
-  int rc2 = persist.finish(hbuf, hdev, out_nchw, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream);
+  int rc2 = persist.finish(hbuf, hdev, out_nchw, batch, psync, f->ks, stream, /*sync_is_zero=*/true);
   if (rc == ODEHIP_OK && rc2 == ODEHIP_OK) {
     float* const regions[1] = {out_nchw};
     const size_t floats[1] = {(size_t)n_times * st_f};

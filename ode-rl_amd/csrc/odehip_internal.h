@@ -134,8 +134,10 @@ extern unsigned long long* g_debug_buf;
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 int check_stack(const odehip_convstack* f);
-// NCHW -> Q4 and, in the same launch, a verbatim NCHW copy (solution[0] = y0)
-int nchw_to_q4_and_copy(const float* src, float* dst_q4, float* copy_nchw, int batch, int channels, hipStream_t stream);
+// prologue of a fixed-grid trajectory in one launch: NCHW -> Q4 + verbatim copy (solution[0] = y0), n_h <= 64 step sizes into hdev,
+// n_zero words zeroed (the persistent launch's flag area; may be null)
+int traj_prologue(const float* src, float* dst_q4, float* copy_nchw, int batch, int channels, const float* h_host, int n_h, float* hdev,
+                  unsigned* zero_words, int n_zero, hipStream_t stream);
 int max_hidden(const odehip_convstack* f);
 int upload_floats(float* dst, const float* src, int n, hipStream_t stream);  // scalars travel as kernel arguments (async)
 // f(x) with the stage combine fused into the last conv; `hidden` (n_convs-1 buffers) keeps the ReLU outputs for a backward pass

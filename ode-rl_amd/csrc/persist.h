@@ -24,7 +24,9 @@ class PersistScope {
   bool active() const { return active_; }
   // hbuf / hdev: host copy and device array of the step sizes (fixed grids: the table gets h by value), or null / null when the
   // step size only exists on the device (dopri5); out_nchw may be null; sync: persist_sync_bytes(batch) of workspace
-  int finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream);
+  // sync_is_zero: the caller has already zeroed the flag area on this stream (traj_prologue)
+  int finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream,
+             bool sync_is_zero = false);
   // Enqueued behind a call's last kernel when finish() took the persistent path: if a capped wait of a persistent launch has
   // given up (the mapped error word is set; never expected) the regions are filled with NaN, so the call that produced the
   // invalid result cannot hand plausible-looking numbers to its caller.  No-op when nothing was launched persistently.

@@ -179,7 +179,8 @@ int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, i
     return ODEHIP_OK;
   }
 
-int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream) {
+int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, int batch, unsigned* sync, int ks, hipStream_t stream,
+                         bool sync_is_zero) {
     if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;
     if (!active_) return ODEHIP_OK;
     active_ = false;
@@ -238,7 +239,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     }
     int rc;
     if (table) {
-      ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
+      if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
                                kPersistGrid, stream);
       if (rc == ODEHIP_OK) {
