@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 4 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 5 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -361,6 +361,30 @@ int odehip_warp_composite_backward(const float* pred_outputs, const float* start
                                    const float* grid_y, const float* grad_pred_x, const float* grad_warped, const float* grad_masks,
                                    int batch, int n_times, int channels, int height, int width, float* grad_pred_outputs,
                                    float* grad_start_image, void* stream);
+
+/* ---- the conv encoder / decoder either side of the path (models/ODEConvGRU.py:101-118 Encoder, :121-140 Decoder; n_downs = 2) --
+ * Each is ONE fused launch: the 32x32 intermediate stays in LDS, the 16 -> out_ch and in_ch -> 32 layers run on the fp32 MFMA.
+ * Frames are 64x64, latents 16x16 (the path's fixed map size).  LeakyReLU slope: the reference's 0.2.
+ *
+ * Encoder: Conv2d(in_ch, 16, 3, 2, 1) -> LeakyReLU -> Conv2d(16, out_ch, 3, 2, 1) -> LeakyReLU.  w1 (16, in_ch, 3, 3), b1 (16),
+ * w2 (out_ch, 16, 3, 3), b2 (out_ch) as nn.Conv2d holds them; in_ch 1..4, out_ch 32 / 64 / 128.  `pack` (device,
+ * odehip_frame_encoder_pack_floats floats) is refreshed by odehip_pack_frame_encoder whenever the parameters change.
+ * frames (B, T, in_ch, 64, 64) -- the reference's inputs.view(b*t, c, h, w) (:63) -- and the result is written TIME-FIRST,
+ * (T, B, out_ch, 16, 16) contiguous: what :64-68 produce as a permuted view and odehip_odeconvgru_encode consumes. */
+size_t odehip_frame_encoder_pack_floats(int in_ch, int out_ch);
+int odehip_pack_frame_encoder(const float* w1, const float* b1, const float* w2, const float* b2, int in_ch, int out_ch, float* pack,
+                              void* stream);
+int odehip_frame_encode(const float* pack, const float* frames, int batch, int n_frames, int in_ch, int out_ch, float negative_slope,
+                        float* out_time_first, void* stream);
+/* Decoder: ConvTranspose2d(in_ch, 32, 4, 2, 1) -> LeakyReLU -> ConvTranspose2d(32, out_ch, 4, 2, 1) [-> sigmoid if apply_sigmoid:
+ * the F.sigmoid of :85].  w1 (in_ch, 32, 4, 4), b1 (32), w2 (32, out_ch, 4, 4), b2 (out_ch) as nn.ConvTranspose2d holds them;
+ * in_ch 32 / 64 / 128, out_ch 1..4.  latents (N, in_ch, 16, 16) -- the solver's (T, B, C, 16, 16) as it lies, N = T*B (:84) --
+ * -> out (N, out_ch, 64, 64). */
+size_t odehip_frame_decoder_pack_floats(int in_ch, int out_ch);
+int odehip_pack_frame_decoder(const float* w1, const float* b1, const float* w2, const float* b2, int in_ch, int out_ch, float* pack,
+                              void* stream);
+int odehip_frame_decode(const float* pack, const float* latents, int n_images, int in_ch, int out_ch, float negative_slope,
+                        int apply_sigmoid, float* out, void* stream);
 
 /* odehip_odeint_fixed runs a forward-only trajectory of a 64-channel fp32 stack as ONE persistent launch (the four workgroups of a
  * sample hand layers to each other through L2 instead of through launch boundaries).  On by default

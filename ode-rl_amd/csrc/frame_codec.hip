@@ -1,0 +1,478 @@
+// frame_codec.hip -- the conv encoder / decoder either side of the path, each as ONE fused launch.
+//
+//   Encoder (/root/reference/models/ODEConvGRU.py:101-118, n_downs = 2):
+//       Conv2d(in_ch, 16, 3, 2, 1) -> LeakyReLU(0.2) -> Conv2d(16, out_ch, 3, 2, 1) -> LeakyReLU(0.2)      64x64 -> 32x32 -> 16x16
+//   Decoder (:121-140, n_ups = 2):
+//       ConvTranspose2d(in_ch, 32, 4, 2, 1) -> LeakyReLU(0.2) -> ConvTranspose2d(32, out_ch, 4, 2, 1) [-> sigmoid, :85]
+//                                                                                                       16x16 -> 32x32 -> 64x64
+// Unfused these are four library launches that write the 32x32 intermediate (16 resp. 32 channels: 2x / 4x the bytes of the
+// latent) to HBM and read it back.  Here the intermediate lives in LDS; the two layers with the arithmetic (16 -> out_ch and
+// in_ch -> 32) run on the exact-fp32 MFMA, the two one-channel-sided layers on the VALU.  The encoder writes its result
+// TIME-FIRST (T,B,C,16,16) -- what ODEConvGRUCell consumes (ODEConvGRU.py:68 permutes a view) -- and the decoder reads the
+// solver's (T,B,C,16,16) as it lies: no layout copy on either side.
+//
+// MFMA operand trick used by both: activations sit in LDS as channel quads ([quad][y][x] x 4 floats).  Lane (n = pixel of a
+// 16-pixel block, kq = lane / 16) reads ONE 16-byte quad `kq` of its (shifted) input pixel: component j of it is its B value for
+// the j-th of four v_mfma_f32_16x16x4_f32, whose k index therefore runs over channels {j, 4 + j, 8 + j, 12 + j} of a 16-channel
+// group -- any fixed permutation of k is fine as long as the weights are packed the same way, which the pack kernels below do.
+#include <stddef.h>
+
+#include "conv_common.h"
+
+namespace odehip {
+
+constexpr int kFrame = 64;     // frames are 64x64: two stride-2 layers take them to the path's 16x16 latents
+constexpr int kHalf = 32;      // the intermediate resolution
+constexpr int kEncMid = 16;    // Encoder: chan = 16 (ODEConvGRU.py:105)
+constexpr int kDecMid = 32;    // Decoder: chan = 32 (:131)
+constexpr int kCodecThreads = 256;
+
+// ConvTranspose2d(k = 4, stride 2, pad 1): output row 2 i + a receives input row i + d through kernel row k, for two (k, d) per
+// parity a (o = 2 iy - 1 + k):  a = 0: (1, 0), (3, -1);   a = 1: (0, +1), (2, 0).  Same for columns.
+__host__ __device__ __forceinline__ void convt_tap(int parity, int t, int& k, int& d) {
+  if (parity == 0) { k = t == 0 ? 1 : 3; d = t == 0 ? 0 : -1; }
+  else             { k = t == 0 ? 0 : 2; d = t == 0 ? 1 : 0; }
+}
+
+__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.0f ? v : v * slope; }
+
+// ------------------------------------------------------------------------------------------------------------------ packing
+// Encoder pack (floats): [w1 (16, in_ch, 3, 3) as is | b1 (16) | pad to x4 | A2 [tap 9][kq 4][co][j 4] = w2[co][4 kq + j][tap] | b2]
+__host__ __device__ inline size_t enc_off_b1(int in_ch) { return (size_t)kEncMid * in_ch * 9; }
+__host__ __device__ inline size_t enc_off_a2(int in_ch) { return (enc_off_b1(in_ch) + kEncMid + 3) & ~(size_t)3; }
+__host__ __device__ inline size_t enc_off_b2(int in_ch, int out_ch) { return enc_off_a2(in_ch) + (size_t)9 * 16 * out_ch; }
+__host__ __device__ inline size_t enc_pack_floats(int in_ch, int out_ch) { return enc_off_b2(in_ch, out_ch) + out_ch; }
+
+__global__ void pack_frame_encoder_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                          const float* __restrict__ b2, int in_ch, int out_ch, float* __restrict__ dst) {
+  const size_t n = enc_pack_floats(in_ch, out_ch);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (i < enc_off_b1(in_ch)) v = w1[i];
+    else if (i < enc_off_b1(in_ch) + kEncMid) v = b1[i - enc_off_b1(in_ch)];
+    else if (i < enc_off_a2(in_ch)) v = 0.0f;
+    else if (i < enc_off_b2(in_ch, out_ch)) {
+      const size_t e = i - enc_off_a2(in_ch);
+      const int j = (int)(e & 3), co = (int)((e >> 2) % out_ch), kq = (int)((e >> 2) / out_ch & 3), tap = (int)((e >> 2) / out_ch >> 2);
+      v = w2[((size_t)co * kEncMid + 4 * kq + j) * 9 + tap];
+    } else v = b2[i - enc_off_b2(in_ch, out_ch)];
+    dst[i] = v;
+  }
+}
+
+// Decoder pack (floats): [A1 [parity 4][tap 4][g][kq 4][co 32][j 4] = w1[16 g + 4 kq + j][co][ky][kx] | b1 (32) |
+//                         W2 [parity 4][tap 4][o][ci 32] = w2[ci][o][ky][kx] | b2 (out_ch)]      (ky, kx) = convt_tap(parity, tap)
+__host__ __device__ inline size_t dec_off_b1(int in_ch) { return (size_t)in_ch * 512; }
+__host__ __device__ inline size_t dec_off_w2(int in_ch) { return dec_off_b1(in_ch) + kDecMid; }
+__host__ __device__ inline size_t dec_off_b2(int in_ch, int out_ch) { return dec_off_w2(in_ch) + (size_t)16 * out_ch * kDecMid; }
+__host__ __device__ inline size_t dec_pack_floats(int in_ch, int out_ch) { return (dec_off_b2(in_ch, out_ch) + out_ch + 3) & ~(size_t)3; }
+
+__global__ void pack_frame_decoder_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                          const float* __restrict__ b2, int in_ch, int out_ch, float* __restrict__ dst) {
+  const size_t n = dec_pack_floats(in_ch, out_ch);
+  const int G = in_ch / 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (i < dec_off_b1(in_ch)) {
+      size_t e = i;
+      const int j = (int)(e & 3); e >>= 2;
+      const int co = (int)(e % kDecMid); e /= kDecMid;
+      const int kq = (int)(e & 3); e >>= 2;
+      const int g = (int)(e % G); e /= G;
+      const int tap = (int)(e & 3), par = (int)(e >> 2);
+      int ky, kx, d;
+      convt_tap(par >> 1, tap >> 1, ky, d);
+      convt_tap(par & 1, tap & 1, kx, d);
+      v = w1[(((size_t)(16 * g + 4 * kq + j) * kDecMid + co) * 4 + ky) * 4 + kx];
+    } else if (i < dec_off_w2(in_ch)) v = b1[i - dec_off_b1(in_ch)];
+    else if (i < dec_off_b2(in_ch, out_ch)) {
+      size_t e = i - dec_off_w2(in_ch);
+      const int ci = (int)(e % kDecMid); e /= kDecMid;
+      const int o = (int)(e % out_ch); e /= out_ch;
+      const int tap = (int)(e & 3), par = (int)(e >> 2);
+      int ky, kx, d;
+      convt_tap(par >> 1, tap >> 1, ky, d);
+      convt_tap(par & 1, tap & 1, kx, d);
+      v = w2[(((size_t)ci * out_ch + o) * 4 + ky) * 4 + kx];
+    } else if (i < dec_off_b2(in_ch, out_ch) + out_ch) v = b2[i - dec_off_b2(in_ch, out_ch)];
+    dst[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ encoder
+struct EncArgs {
+  const float* pack;
+  const float* frames;  // (B, T, in_ch, 64, 64)
+  float* out;           // (T, B, out_ch, 16, 16)
+  int batch, n_frames, in_ch;
+  float slope;
+};
+
+constexpr int kImgW = kFrame + 1;   // row / column 0 = the zero border at index -1 (stride 2, pad 1 never reaches index 64)
+constexpr int kMidW = kHalf + 1;
+
+// One workgroup per frame.  LDS: img [in_ch][65][65] floats | mid [quad 4][33][33] x 16 B | A2 [tap 9][kq 4][co] x 16 B.
+template <int COB>  // out_ch / 16
+__global__ __launch_bounds__(kCodecThreads) void frame_encode_kernel(const EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int out_ch = COB * 16;
+  float* const img = (float*)smem;
+  f32x4* const mid = (f32x4*)(smem + (((size_t)a.in_ch * kImgW * kImgW * 4 + 15) & ~(size_t)15));
+  f32x4* const a2 = mid + 4 * kMidW * kMidW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x, b = n / a.n_frames, t = n - b * a.n_frames;
+  typedef const __attribute__((address_space(4))) float ConstF;  // uniform reads of the small weights: scalar loads
+  ConstF* const pk = (ConstF*)a.pack;
+
+  // ---- phase 0: frame -> LDS (with its zero border), conv2's weights -> LDS
+  for (int i = tid; i < a.in_ch * (2 * kImgW - 1); i += kCodecThreads) {
+    const int ic = i / (2 * kImgW - 1), e = i - ic * (2 * kImgW - 1);
+    img[(size_t)ic * kImgW * kImgW + (e < kImgW ? e : (e - kImgW + 1) * kImgW)] = 0.0f;
+  }
+  for (int i = tid; i < 4 * (2 * kMidW - 1); i += kCodecThreads) {
+    const int q = i / (2 * kMidW - 1), e = i - q * (2 * kMidW - 1);
+    mid[q * kMidW * kMidW + (e < kMidW ? e : (e - kMidW + 1) * kMidW)] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* const src = a.frames + (size_t)n * a.in_ch * kFrame * kFrame;
+  for (int i = tid; i < a.in_ch * kFrame * kFrame / 4; i += kCodecThreads) {
+    const int ic = i / (kFrame * kFrame / 4), e = i - ic * (kFrame * kFrame / 4), r = e / (kFrame / 4), c4 = e - r * (kFrame / 4);
+    const f32x4 v = *(const f32x4*)(src + (size_t)i * 4);
+    float* d = img + (size_t)ic * kImgW * kImgW + (r + 1) * kImgW + 4 * c4 + 1;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  {
+    const f32x4* const g = (const f32x4*)(a.pack + enc_off_a2(a.in_ch));
+    for (int i = tid; i < 9 * 4 * out_ch; i += kCodecThreads) a2[i] = g[i];
+  }
+  __syncthreads();
+
+  // ---- phase 1: Conv2d(in_ch, 16, 3, 2, 1) + LeakyReLU on the VALU: 4 output pixels per thread, all 16 channels
+  for (int s = 0; s < kHalf * kHalf / kCodecThreads; ++s) {
+    const int p = tid + s * kCodecThreads, oy = p / kHalf, ox = p - oy * kHalf;
+    float acc[kEncMid];
+#pragma unroll
+    for (int c = 0; c < kEncMid; ++c) acc[c] = pk[enc_off_b1(a.in_ch) + c];
+    for (int ic = 0; ic < a.in_ch; ++ic) {
+      const float* ip = img + (size_t)ic * kImgW * kImgW + 2 * oy * kImgW + 2 * ox;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float v = ip[(k / 3) * kImgW + (k % 3)];
+#pragma unroll
+        for (int c = 0; c < kEncMid; ++c) acc[c] = __builtin_fmaf(pk[(c * a.in_ch + ic) * 9 + k], v, acc[c]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      mid[(q * kMidW + oy + 1) * kMidW + ox + 1] =
+          f32x4{leaky(acc[4 * q], a.slope), leaky(acc[4 * q + 1], a.slope), leaky(acc[4 * q + 2], a.slope), leaky(acc[4 * q + 3], a.slope)};
+  }
+  __syncthreads();
+
+  // ---- phase 2: Conv2d(16, out_ch, 3, 2, 1) on the MFMA: wave w owns output rows 4w..4w+3 (one 16-pixel block each) x all co
+  const int nn = lane & 15, kq = lane >> 4;
+  f32x4 acc[COB][4];
+#pragma unroll
+  for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[cb][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap % 3;
+    f32x4 bf[4], af[COB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf[r] = mid[(kq * kMidW + 2 * (4 * wave + r) + ky) * kMidW + 2 * nn + kx];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb) af[cb] = a2[(tap * 4 + kq) * out_ch + cb * 16 + nn];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb].x, bf[r].x, acc[cb][r], 0, 0, 0);
+        acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb].y, bf[r].y, acc[cb][r], 0, 0, 0);
+        acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb].z, bf[r].z, acc[cb][r], 0, 0, 0);
+        acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cb].w, bf[r].w, acc[cb][r], 0, 0, 0);
+      }
+  }
+  // lane (nn, kq) holds channels cb*16 + 4 kq + i of pixel (row, nn); time-first destination
+  float* const dst = a.out + ((size_t)t * a.batch + b) * out_ch * 256;
+#pragma unroll
+  for (int cb = 0; cb < COB; ++cb) {
+    const int c0 = cb * 16 + 4 * kq;
+    const f32x4 bias = *(const f32x4*)(a.pack + enc_off_b2(a.in_ch, out_ch) + c0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 v = acc[cb][r] + bias;
+      float* o = dst + (size_t)c0 * 256 + (4 * wave + r) * 16 + nn;
+      o[0] = leaky(v.x, a.slope); o[256] = leaky(v.y, a.slope); o[512] = leaky(v.z, a.slope); o[768] = leaky(v.w, a.slope);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ decoder
+struct DecArgs {
+  const float* pack;
+  const float* latents;  // (N, in_ch, 16, 16)
+  float* out;            // (N, out_ch, 64, 64)
+  int n_images, in_ch, out_ch;
+  float slope;
+  int sigmoid;
+};
+
+constexpr int kZRows = 6, kZW = 18;          // latent rows 4q-1 .. 4q+4, columns -1 .. 16
+constexpr int kMRows = 10, kMW = 34;         // intermediate rows 8q-1 .. 8q+8, columns -1 .. 32
+constexpr int kMPix = 36;                    // floats per intermediate pixel (32 channels + 4: a 2-pixel lane stride is 72 words)
+
+// One workgroup per (image, quarter q of the output rows): output rows 16q .. 16q+15 need intermediate rows 8q-1 .. 8q+8, which
+// need latent rows 4q-1 .. 4q+4.  LDS: z [quad in_ch/4][6][18] x 16 B | mid [10][34][36] floats: 76 KiB at in_ch = 64, two
+// workgroups per CU.  ConvTranspose(k4, s2, p1) = four 2x2 convolutions, one per output parity: wave w takes parity (w >> 1, w & 1)
+// in both layers, so its weights are one contiguous quarter of the pack (layer 1: 16-byte fragments straight from L2; layer 2:
+// wave-uniform scalar loads).
+template <int G>  // in_ch / 16
+__global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_kernel(const DecArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int in_ch = G * 16;
+  f32x4* const z = (f32x4*)smem;
+  float* const mid = (float*)(smem + (size_t)4 * G * kZRows * kZW * 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int pa = wave >> 1, pb = wave & 1;
+
+  // ---- phase 0: latent rows -> LDS as channel quads, zero outside the image; the intermediate's border columns
+  for (int i = tid; i < 4 * G * kZRows * kZW; i += kCodecThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < kMRows * 2; i += kCodecThreads) {
+    float* m = mid + ((i >> 1) * kMW + (i & 1) * (kMW - 1)) * kMPix;
+#pragma unroll
+    for (int c = 0; c < kDecMid; c += 4) *(f32x4*)(m + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const float* const src = a.latents + (size_t)n * in_ch * 256;
+  for (int i = tid; i < in_ch * kZRows * 4; i += kCodecThreads) {
+    const int ci = i / (kZRows * 4), e = i - ci * (kZRows * 4), rr = e >> 2, c4 = e & 3;
+    const int zr = 4 * q - 1 + rr;
+    if (zr < 0 || zr > 15) continue;
+    const f32x4 v = *(const f32x4*)(src + (size_t)ci * 256 + zr * 16 + 4 * c4);
+    float* d = (float*)(z + ((ci >> 2) * kZRows + rr) * kZW + 4 * c4 + 1) + (ci & 3);
+    d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+  }
+  __syncthreads();
+
+  // ---- phase 1: ConvTranspose2d(in_ch, 32, 4, 2, 1) + LeakyReLU on the MFMA.  This wave: the five intermediate rows of parity pa
+  // (local rows mr = 2 r + 1 - pa; row 8q-1 is odd), columns of parity pb (16 per row = one block), both 16-channel halves.
+  {
+    const int nn = lane & 15, kq = lane >> 4;
+    f32x4 acc[2][5];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 5; ++r) acc[cb][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* const a1 = (const f32x4*)a.pack + (size_t)(pa * 2 + pb) * 4 * G * 4 * kDecMid + kq * kDecMid + nn;
+    // the weight fragments come straight from L2: those of the next tap are requested before this tap's MFMAs
+    f32x4 af[G][2], afn[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) af[g][cb] = a1[g * 4 * kDecMid + cb * 16];
+#pragma unroll 1
+    for (int tap = 0; tap < 4; ++tap) {
+      int ky, kx, dy, dx;
+      convt_tap(pa, tap >> 1, ky, dy);
+      convt_tap(pb, tap & 1, kx, dx);
+      (void)ky; (void)kx;
+      if (tap + 1 < 4) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) afn[g][cb] = a1[((tap + 1) * G + g) * 4 * kDecMid + cb * 16];
+      }
+      // intermediate row my = 8q - 1 + mr = 2 i' + pa (mr = 2 r + 1 - pa)  ->  latent row i' + dy, local index r - pa + 1 + dy
+      const f32x4* const zb = z + (kq * kZRows + 1 - pa + dy) * kZW + nn + dx + 1;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        f32x4 bf[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) bf[r] = zb[(4 * g * kZRows + r) * kZW];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].x, bf[r].x, acc[cb][r], 0, 0, 0);
+            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].y, bf[r].y, acc[cb][r], 0, 0, 0);
+            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].z, bf[r].z, acc[cb][r], 0, 0, 0);
+            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].w, bf[r].w, acc[cb][r], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) af[g][cb] = afn[g][cb];
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int c0 = cb * 16 + 4 * kq;
+      const f32x4 bias = *(const f32x4*)(a.pack + dec_off_b1(in_ch) + c0);
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int mr = 2 * r + 1 - pa, my = 8 * q - 1 + mr;
+        f32x4 v = acc[cb][r] + bias;
+        v = f32x4{leaky(v.x, a.slope), leaky(v.y, a.slope), leaky(v.z, a.slope), leaky(v.w, a.slope)};
+        if (my < 0 || my >= kHalf) v = f32x4{0.f, 0.f, 0.f, 0.f};  // rows beyond the intermediate image contribute nothing
+        *(f32x4*)(mid + (mr * kMW + 2 * nn + pb + 1) * kMPix + c0) = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: ConvTranspose2d(32, out_ch, 4, 2, 1) [+ sigmoid] on the VALU.  This wave: output pixels (16q + 2 il + pa,
+  // 2 j + pb), il = 0..7, j = 0..31: four per lane.  Weights of its parity: [tap 4][o][ci 32], wave-uniform.
+  {
+    typedef const __attribute__((address_space(4))) float ConstF;
+    ConstF* const w2 = (ConstF*)(a.pack + dec_off_w2(in_ch)) + (size_t)(pa * 2 + pb) * 4 * a.out_ch * kDecMid;
+    ConstF* const b2 = (ConstF*)(a.pack + dec_off_b2(in_ch, a.out_ch));
+    const int j = lane & 31, ih = lane >> 5;
+    for (int o = 0; o < a.out_ch; ++o) {
+      float accv[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) accv[s] = b2[o];
+#pragma unroll 1
+      for (int tap = 0; tap < 4; ++tap) {
+        int ky, kx, dy, dx;
+        convt_tap(pa, tap >> 1, ky, dy);
+        convt_tap(pb, tap & 1, kx, dx);
+        (void)ky; (void)kx;
+        ConstF* const w = w2 + (tap * a.out_ch + o) * kDecMid;
+        // output row 16q + 2 il + pa = 2 (8q + il) + pa  ->  intermediate row 8q + il + dy, local index il + dy + 1 (il = ih + 2 s)
+        const float* const mb = mid + ((ih + dy + 1) * kMW + j + dx + 1) * kMPix;
+#pragma unroll
+        for (int c = 0; c < kDecMid; c += 4) {
+          const float w0 = w[c], w1 = w[c + 1], w2v = w[c + 2], w3 = w[c + 3];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const f32x4 mv = *(const f32x4*)(mb + 2 * s * kMW * kMPix + c);
+            accv[s] = __builtin_fmaf(mv.x, w0, accv[s]);
+            accv[s] = __builtin_fmaf(mv.y, w1, accv[s]);
+            accv[s] = __builtin_fmaf(mv.z, w2v, accv[s]);
+            accv[s] = __builtin_fmaf(mv.w, w3, accv[s]);
+          }
+        }
+      }
+      float* const dst = a.out + ((size_t)n * a.out_ch + o) * kFrame * kFrame;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float v = accv[s];
+        if (a.sigmoid) v = 1.0f / (1.0f + expf(-v));
+        dst[(16 * q + 2 * (ih + 2 * s) + pa) * kFrame + 2 * j + pb] = v;
+      }
+    }
+  }
+}
+
+static size_t enc_lds_bytes(int in_ch, int out_ch) {
+  return (((size_t)in_ch * kImgW * kImgW * 4 + 15) & ~(size_t)15) + (size_t)4 * kMidW * kMidW * 16 + (size_t)9 * 4 * out_ch * 16;
+}
+static size_t dec_lds_bytes(int in_ch) { return (size_t)(in_ch / 4) * kZRows * kZW * 16 + (size_t)kMRows * kMW * kMPix * 4; }
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return ODEHIP_OK;
+}
+
+}  // namespace odehip
+
+using namespace odehip;
+
+extern "C" size_t odehip_frame_encoder_pack_floats(int in_ch, int out_ch) {
+  return (in_ch >= 1 && out_ch >= 16) ? enc_pack_floats(in_ch, out_ch) : 0;
+}
+extern "C" size_t odehip_frame_decoder_pack_floats(int in_ch, int out_ch) {
+  return (in_ch >= 16 && out_ch >= 1) ? dec_pack_floats(in_ch, out_ch) : 0;
+}
+
+static int check_encoder_shape(const char* who, int in_ch, int out_ch) {
+  ODEHIP_REQUIRE(in_ch >= 1 && in_ch <= 4, "%s: 1..4 frame channels (got %d)", who, in_ch);
+  ODEHIP_REQUIRE(out_ch == 32 || out_ch == 64 || out_ch == 128, "%s: 32, 64 or 128 latent channels (got %d)", who, out_ch);
+  ODEHIP_REQUIRE(enc_lds_bytes(in_ch, out_ch) <= 160 * 1024, "%s: in_ch %d with out_ch %d does not fit in LDS", who, in_ch, out_ch);
+  return ODEHIP_OK;
+}
+static int check_decoder_shape(const char* who, int in_ch, int out_ch) {
+  ODEHIP_REQUIRE(in_ch == 32 || in_ch == 64 || in_ch == 128, "%s: 32, 64 or 128 latent channels (got %d)", who, in_ch);
+  ODEHIP_REQUIRE(out_ch >= 1 && out_ch <= 4, "%s: 1..4 frame channels (got %d)", who, out_ch);
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_pack_frame_encoder(const float* w1, const float* b1, const float* w2, const float* b2, int in_ch, int out_ch,
+                                         float* pack, void* stream) {
+  ODEHIP_REQUIRE(w1 && b1 && w2 && b2 && pack, "pack_frame_encoder: null pointer argument");
+  int rc = check_encoder_shape("pack_frame_encoder", in_ch, out_ch);
+  if (rc != ODEHIP_OK) return rc;
+  hipLaunchKernelGGL(pack_frame_encoder_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, in_ch, out_ch, pack);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_pack_frame_decoder(const float* w1, const float* b1, const float* w2, const float* b2, int in_ch, int out_ch,
+                                         float* pack, void* stream) {
+  ODEHIP_REQUIRE(w1 && b1 && w2 && b2 && pack, "pack_frame_decoder: null pointer argument");
+  int rc = check_decoder_shape("pack_frame_decoder", in_ch, out_ch);
+  if (rc != ODEHIP_OK) return rc;
+  hipLaunchKernelGGL(pack_frame_decoder_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, in_ch, out_ch, pack);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_frame_encode(const float* pack, const float* frames, int batch, int n_frames, int in_ch, int out_ch,
+                                   float negative_slope, float* out_time_first, void* stream) {
+  ODEHIP_REQUIRE(pack && frames && out_time_first, "frame_encode: null pointer argument");
+  ODEHIP_REQUIRE(batch > 0 && n_frames > 0, "frame_encode: batch and n_frames must be positive");
+  int rc = check_encoder_shape("frame_encode", in_ch, out_ch);
+  if (rc != ODEHIP_OK) return rc;
+  EncArgs a;
+  a.pack = pack; a.frames = frames; a.out = out_time_first; a.batch = batch; a.n_frames = n_frames; a.in_ch = in_ch; a.slope = negative_slope;
+  const size_t lds = enc_lds_bytes(in_ch, out_ch);
+  const dim3 grid((unsigned)(batch * n_frames));
+  static bool attr[3] = {false, false, false};
+#define ODEHIP_ENC_LAUNCH(COB, slot)                                                                       \
+  {                                                                                                       \
+    if (!attr[slot]) {                                                                                    \
+      rc = set_lds(frame_encode_kernel<COB>, 160 * 1024);                                                 \
+      if (rc != ODEHIP_OK) return rc;                                                                     \
+      attr[slot] = true;                                                                                  \
+    }                                                                                                     \
+    hipLaunchKernelGGL(frame_encode_kernel<COB>, grid, dim3(kCodecThreads), lds, (hipStream_t)stream, a); \
+  }
+  if (out_ch == 32) ODEHIP_ENC_LAUNCH(2, 0)
+  else if (out_ch == 64) ODEHIP_ENC_LAUNCH(4, 1)
+  else ODEHIP_ENC_LAUNCH(8, 2)
+#undef ODEHIP_ENC_LAUNCH
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_frame_decode(const float* pack, const float* latents, int n_images, int in_ch, int out_ch, float negative_slope,
+                                   int apply_sigmoid, float* out, void* stream) {
+  ODEHIP_REQUIRE(pack && latents && out, "frame_decode: null pointer argument");
+  ODEHIP_REQUIRE(n_images > 0, "frame_decode: n_images must be positive");
+  int rc = check_decoder_shape("frame_decode", in_ch, out_ch);
+  if (rc != ODEHIP_OK) return rc;
+  DecArgs a;
+  a.pack = pack; a.latents = latents; a.out = out; a.n_images = n_images; a.in_ch = in_ch; a.out_ch = out_ch; a.slope = negative_slope;
+  a.sigmoid = apply_sigmoid;
+  const size_t lds = dec_lds_bytes(in_ch);
+  const dim3 grid((unsigned)n_images * 4);
+  static bool attr[3] = {false, false, false};
+#define ODEHIP_DEC_LAUNCH(G, slot)                                                                       \
+  {                                                                                                     \
+    if (!attr[slot]) {                                                                                  \
+      rc = set_lds(frame_decode_kernel<G>, 160 * 1024);                                                 \
+      if (rc != ODEHIP_OK) return rc;                                                                   \
+      attr[slot] = true;                                                                                \
+    }                                                                                                   \
+    hipLaunchKernelGGL(frame_decode_kernel<G>, grid, dim3(kCodecThreads), lds, (hipStream_t)stream, a); \
+  }
+  if (in_ch == 32) ODEHIP_DEC_LAUNCH(2, 0)
+  else if (in_ch == 64) ODEHIP_DEC_LAUNCH(4, 1)
+  else ODEHIP_DEC_LAUNCH(8, 2)
+#undef ODEHIP_DEC_LAUNCH
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}

@@ -818,3 +818,95 @@ def warp_composite_backward(pred_outputs, start_image, warped, grid_x, grid_y, g
                                                           _ptr(g_pred_x), _ptr(g_warped), _ptr(g_masks), b, t, c, h, w, _ptr(g_po),
                                                           _ptr(g_start), _stream()))
     return g_po, g_start
+
+
+# ---- the conv encoder / decoder either side of the path (models/ODEConvGRU.py:101-140), one fused launch each ------------------
+_codec_packs = {}   # id(module) -> (weakref to module, stamp, pack tensor)
+
+
+def _codec_layers(seq, conv_type, kernel, n_mid):
+    """The (conv, act, conv[, act]) structure of the reference's Encoder / Decoder with n_downs = n_ups = 2, or None."""
+    mods = list(seq)
+    if len(mods) not in (3, 4) or not isinstance(mods[0], conv_type) or not isinstance(mods[2], conv_type):
+        return None
+    if not all(isinstance(m, torch.nn.LeakyReLU) for m in mods[1::2]):
+        return None
+    c1, c2 = mods[0], mods[2]
+    for c in (c1, c2):
+        if c.kernel_size != (kernel, kernel) or c.stride != (2, 2) or c.padding != (1, 1) or c.bias is None or c.groups != 1 \
+                or c.dilation != (1, 1) or (conv_type is torch.nn.ConvTranspose2d and c.output_padding != (0, 0)):
+            return None
+    if c1.out_channels != n_mid or c2.in_channels != n_mid or len({m.negative_slope for m in mods[1::2]}) != 1:
+        return None
+    return c1, c2, float(mods[1].negative_slope)
+
+
+def frame_encoder_supported(seq):
+    ls = _codec_layers(seq, torch.nn.Conv2d, 3, 16)
+    return ls is not None and len(list(seq)) == 4 and 1 <= ls[0].in_channels <= 4 and ls[1].out_channels in (32, 64, 128)
+
+
+def frame_decoder_supported(seq):
+    ls = _codec_layers(seq, torch.nn.ConvTranspose2d, 4, 32)
+    return ls is not None and len(list(seq)) == 3 and ls[0].in_channels in (32, 64, 128) and 1 <= ls[1].out_channels <= 4
+
+
+def _codec_pack(seq, c1, c2, n_floats, pack_fn, in_ch, out_ch):
+    import weakref
+    params = (c1.weight, c1.bias, c2.weight, c2.bias)
+    for p in params:
+        require_device_tensor(p, "codec parameter")
+    stamp = tuple((p.data_ptr(), p._version) for p in params)
+    ent = _codec_packs.get(id(seq))
+    if ent is not None and ent[0]() is seq and ent[1] == stamp:
+        return ent[2]
+    pack = torch.empty(int(n_floats), dtype=torch.float32, device=c1.weight.device)
+    _lib.check(pack_fn(_ptr(c1.weight.detach().contiguous()), _ptr(c1.bias.detach().contiguous()), _ptr(c2.weight.detach().contiguous()),
+                       _ptr(c2.bias.detach().contiguous()), in_ch, out_ch, _ptr(pack), _stream()))
+    if len(_codec_packs) > 32:
+        for k in [k for k, v in _codec_packs.items() if v[0]() is None]:
+            del _codec_packs[k]
+    _codec_packs[id(seq)] = (weakref.ref(seq), stamp, pack)
+    return pack
+
+
+def frame_encode(seq, frames):
+    """`seq` = the reference Encoder's nn.Sequential (n_downs = 2).  frames (B,T,c,64,64) -> (T,B,out_ch,16,16) contiguous,
+    TIME-FIRST: the layout ODEConvGRU.py:64-68 reaches through a permuted view."""
+    require_device_tensor(frames, "frames")
+    if not frame_encoder_supported(seq):
+        raise ValueError("frame_encode: not the reference's Encoder structure (Conv2d 3/2/1 -> LeakyReLU -> Conv2d 3/2/1 -> LeakyReLU)")
+    c1, c2, slope = _codec_layers(seq, torch.nn.Conv2d, 3, 16)
+    if frames.dim() != 5 or frames.shape[2] != c1.in_channels or tuple(frames.shape[3:]) != (64, 64):
+        raise ValueError(f"frame_encode: frames must be (B,T,{c1.in_channels},64,64), got {tuple(frames.shape)}")
+    frames = frames.detach().contiguous()
+    b, t = frames.shape[:2]
+    lib = _lib.load()
+    pack = _codec_pack(seq, c1, c2, lib.odehip_frame_encoder_pack_floats(c1.in_channels, c2.out_channels), lib.odehip_pack_frame_encoder,
+                       c1.in_channels, c2.out_channels)
+    out = torch.empty((t, b, c2.out_channels, 16, 16), dtype=torch.float32, device=frames.device)
+    _lib.check(lib.odehip_frame_encode(_ptr(pack), _ptr(frames), b, t, c1.in_channels, c2.out_channels, slope, _ptr(out), _stream()))
+    return out
+
+
+def frame_decode(seq, latents, apply_sigmoid):
+    """`seq` = the reference Decoder's nn.Sequential (n_ups = 2).  latents (..., C, 16, 16) (any leading dims, e.g. the solver's
+    (T,B)) -> (..., out_ch, 64, 64); apply_sigmoid folds the F.sigmoid of ODEConvGRU.py:85 into the launch."""
+    require_device_tensor(latents, "latents")
+    if not frame_decoder_supported(seq):
+        raise ValueError("frame_decode: not the reference's Decoder structure (ConvTranspose2d 4/2/1 -> LeakyReLU -> ConvTranspose2d 4/2/1)")
+    c1, c2, slope = _codec_layers(seq, torch.nn.ConvTranspose2d, 4, 32)
+    if latents.dim() < 4 or latents.shape[-3] != c1.in_channels or tuple(latents.shape[-2:]) != (16, 16):
+        raise ValueError(f"frame_decode: latents must be (...,{c1.in_channels},16,16), got {tuple(latents.shape)}")
+    latents = latents.detach().contiguous()
+    lead = tuple(latents.shape[:-3])
+    n = 1
+    for d in lead:
+        n *= d
+    lib = _lib.load()
+    pack = _codec_pack(seq, c1, c2, lib.odehip_frame_decoder_pack_floats(c1.in_channels, c2.out_channels), lib.odehip_pack_frame_decoder,
+                       c1.in_channels, c2.out_channels)
+    out = torch.empty(lead + (c2.out_channels, 64, 64), dtype=torch.float32, device=latents.device)
+    _lib.check(lib.odehip_frame_decode(_ptr(pack), _ptr(latents), n, c1.in_channels, c2.out_channels, slope, 1 if apply_sigmoid else 0,
+                                       _ptr(out), _stream()))
+    return out

@@ -1,12 +1,16 @@
 """Harness for end-to-end parity: the wiring of the reference's `models/ODEConvGRU.py:12-140`
 (conv encoder -> ODEConvGRUCell -> DiffEqSolver -> conv decoder -> sigmoid) around the HIP hot path.
 
-The strided encoder / transposed-conv decoder either side of the path are library calls (MIOpen through torch), as
-SURVEY.md section 8 (a11, f2) scopes them; same module names so the reference's state_dict loads, including the aliased
-keys (`diffeq_solver.ode_func.*` == `ode_decoder_func.*`, `ode_convgru_cell.ode_func.*` == `ode_encoder_func.*`)."""
+The strided encoder / transposed-conv decoder either side of the path are ONE fused HIP launch each
+when no gradient is wanted (csrc/frame_codec.hip: the 32x32 intermediate stays in LDS, the encoder writes time-first, the
+decoder reads the solver's (T,B,C,16,16) as it lies and applies the sigmoid); under autograd, and for structures other than
+the reference's n_downs = 2, they are library calls (MIOpen through torch).  Same module names so the reference's state_dict
+loads, including the aliased keys (`diffeq_solver.ode_func.*` == `ode_decoder_func.*`, `ode_convgru_cell.ode_func.*` ==
+`ode_encoder_func.*`)."""
 import torch
 import torch.nn as nn
 
+from .. import hip_ops
 from ..modules.DiffEqSolver import DiffEqSolver, ODEFunc
 from ..modules.ODEConvGRUCell import ODEConvGRUCell
 
@@ -33,6 +37,20 @@ class Encoder(nn.Module):
     def forward(self, x):
         return self.encoder(x)
 
+    def _fused(self, x):
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return x.is_cuda and not wants_grad and tuple(x.shape[-2:]) == (64, 64) and hip_ops.frame_encoder_supported(self.encoder)
+
+    def encode_time_first(self, frames):
+        """frames (B,T,c,H,W) -> (T,B,C',H/4,W/4): `forward` on the flattened frames and the time-first view of
+        ODEConvGRU.py:63-68, as one fused launch where that applies."""
+        if self._fused(frames):
+            return hip_ops.frame_encode(self.encoder, frames)
+        b, t, c, h, w = frames.size()
+        enc = self.encoder(frames.view(b * t, c, h, w))
+        _, c_, h_, w_ = enc.size()
+        return enc.view(b, -1, c_, h_, w_).permute(1, 0, 2, 3, 4)
+
 
 class Decoder(nn.Module):
     def __init__(self, n_inputs, out_ch, n_ups, nonlinear='relu'):
@@ -49,6 +67,16 @@ class Decoder(nn.Module):
 
     def forward(self, x):
         return self.decoder(x)
+
+    def decode_sigmoid(self, sol_y):
+        """sol_y (T,B,C,h,w) -> sigmoid(decoder(sol_y)) as (T,B,c,4h,4w) (ODEConvGRU.py:84-86), one fused launch where that applies."""
+        wants_grad = torch.is_grad_enabled() and (sol_y.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if sol_y.is_cuda and not wants_grad and tuple(sol_y.shape[-2:]) == (16, 16) and hip_ops.frame_decoder_supported(self.decoder):
+            return hip_ops.frame_decode(self.decoder, sol_y, True)
+        t, b, c, h, w = sol_y.size()
+        pred = torch.sigmoid(self.decoder(sol_y.view(b * t, c, h, w)))
+        _, c3, h3, w3 = pred.size()
+        return pred.view(t, b, c3, h3, w3)
 
 
 class ODEConvGRU(nn.Module):
@@ -71,15 +99,10 @@ class ODEConvGRU(nn.Module):
     def forward(self, inputs, batch_dict):
         b, t, c, h, w = inputs.size()
         observed_tp, tp_to_predict = batch_dict['observed_tp'], batch_dict['tp_to_predict']
-        enc = self.conv_encoder(inputs.view(b * t, c, h, w))
-        _, c_, h_, w_ = enc.size()
-        enc = enc.view(b, -1, c_, h_, w_).permute(1, 0, 2, 3, 4)  # time first
+        enc = self.conv_encoder.encode_time_first(inputs)  # time first
         first_point_mu, _ = self.ode_convgru_cell(enc, observed_tp)
         sol_y = self.diffeq_solver(first_point_mu, tp_to_predict)  # (T,B,C,H,W)
-        t2, b2, c2, h2, w2 = sol_y.size()
-        pred = torch.sigmoid(self.conv_decoder(sol_y.view(b2 * t2, c2, h2, w2)))
-        _, c3, h3, w3 = pred.size()
-        return pred.view(t2, b2, c3, h3, w3).permute(1, 0, 2, 3, 4)
+        return self.conv_decoder.decode_sigmoid(sol_y).permute(1, 0, 2, 3, 4)
 
     def get_prediction(self, inputs, batch_dict=None):
         return self(inputs, batch_dict)
