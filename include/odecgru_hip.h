@@ -83,6 +83,11 @@ size_t odehip_winograd_weight_floats(int cout, int cin);
 int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cout, int cin, int transpose_flip, void* stream);
 /* bf16 A-operand image of a 3x3 weight (round to nearest even): cout % 32 == 0, cin % 16 == 0, cin <= 128 is what the
  * bf16 kernel serves; odehip_bf16_weight_bytes(cout, cin) bytes.  transpose_flip as odehip_pack_conv_weight. */
+/* Winograd F(2x2,5x5) form of a 5x5 weight (conv_wino5.hip): U = G g G^T for the points 0, +-1, +-2, inf; cout % 32 == 0,
+ * cin % 8 == 0.  Set as odehip_conv_desc.w_wino of a ks = 5 layer, or as odehip_convgru_cell.w_gates_wino / w_can_wino. */
+size_t odehip_winograd5_weight_floats(int cout, int cin);
+int odehip_pack_conv_weight_winograd5(const float* w_oihw, float* w_wino, int cout, int cin, int transpose_flip, void* stream);
+
 size_t odehip_bf16_weight_bytes(int cout, int cin);
 int odehip_pack_conv_weight_bf16(const float* w_oihw, void* w_bf16, int cout, int cin, int transpose_flip, void* stream);
 /* fused image of a 64 -> 64 3x3 stack: call once per layer with its position `exec_index` in execution order (forward: the
@@ -102,7 +107,7 @@ typedef struct odehip_conv_desc {
   const float* src2;      /* Q4 input, channels [cin1, cin); NULL when cin1 == cin (torch.cat) */
   int cin1, cin, cout, ks, batch;
   const float* w_packed;  /* from odehip_pack_conv_weight                                      */
-  const float* w_wino;    /* from odehip_pack_conv_weight_winograd, or NULL (direct kernel)    */
+  const float* w_wino;    /* from odehip_pack_conv_weight_winograd (ks 3) / _winograd5 (ks 5), or NULL (direct kernel) */
   const void* w_bf16;     /* from odehip_pack_conv_weight_bf16: non-NULL = bf16 operands, fp32 accumulate (3x3) */
   const float* bias;      /* cout floats or NULL                                               */
   float* dst;             /* Q4 output                                                        */
@@ -205,6 +210,8 @@ typedef struct odehip_convgru_cell {
   const float* gn_can_b;
   const void* w_gates_bf16;    /* optional: odehip_pack_conv_weight_bf16_ks images; non-NULL = bf16 operands, fp32 accumulation */
   const void* w_can_bf16;      /*           (5x5 cells with input + hidden <= 128 channels)                                   */
+  const float* w_gates_wino;   /* optional: odehip_pack_conv_weight_winograd5 forms of the two 5x5 weights; non-NULL = Winograd       */
+  const float* w_can_wino;     /*           F(2x2,5x5) in fp32 (36 instead of 100 multiplies per 2x2 outputs; ignored in bf16 mode)  */
 } odehip_convgru_cell;
 
 size_t odehip_convgru_cell_workspace_bytes(const odehip_convgru_cell* c, int batch);

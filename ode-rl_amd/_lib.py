@@ -47,7 +47,8 @@ class ConvGRUCellDesc(ctypes.Structure):
                 ("w_gates", ctypes.c_void_p), ("b_gates", ctypes.c_void_p), ("gn_gates_w", ctypes.c_void_p),
                 ("gn_gates_b", ctypes.c_void_p), ("w_can", ctypes.c_void_p), ("b_can", ctypes.c_void_p),
                 ("gn_can_w", ctypes.c_void_p), ("gn_can_b", ctypes.c_void_p),
-                ("w_gates_bf16", ctypes.c_void_p), ("w_can_bf16", ctypes.c_void_p)]
+                ("w_gates_bf16", ctypes.c_void_p), ("w_can_bf16", ctypes.c_void_p),
+                ("w_gates_wino", ctypes.c_void_p), ("w_can_wino", ctypes.c_void_p)]
 
 
 class EncoderDesc(ctypes.Structure):
@@ -106,6 +107,8 @@ SIGNATURES = {
     "odehip_persistent_error": (ctypes.c_int, [ctypes.c_int]),
     "odehip_warp_composite": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 4),
     "odehip_warp_composite_backward": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3),
+    "odehip_winograd5_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "odehip_pack_conv_weight_winograd5": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_frame_encoder_pack_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "odehip_frame_decoder_pack_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "odehip_pack_frame_encoder": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2),

@@ -433,6 +433,10 @@ int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
       const int rb = launch_bf16_5x5(a, stream);
       if (rb != 1) return rb;
     }
+    if (a.w_wino && !(g_debug_flags & 64)) {
+      const int rw = launch_wino5(a, stream);
+      if (rw != 1) return rw;
+    }
     if (a.batch * (a.qout / 8) * 2 > 256 && !(g_debug_flags & 32)) return launch_ring<5, 1, 2, 2>(a, stream);
     return launch_ring<5, 1, 4>(a, stream);
   }

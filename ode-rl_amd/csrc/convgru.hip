@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void split_mean_std_kernel(const float* __rest
 }
 
 static int conv_layer(const float* src1, const float* src2, int cin1, int cin, int cout, int ks, const float* wp,
-                      const float* bias, float* dst, int relu, int batch, hipStream_t stream, const void* w_bf16 = nullptr) {
+                      const float* bias, float* dst, int relu, int batch, hipStream_t stream, const void* w_bf16 = nullptr,
+                      const float* w_wino = nullptr) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.src1 = src1;
@@ -140,6 +141,7 @@ static int conv_layer(const float* src1, const float* src2, int cin1, int cin, i
   a.qout = cout / 4;
   a.w_packed = wp;
   a.w_bf16 = w_bf16;
+  a.w_wino = w_wino;
   a.bias = bias;
   a.dst = dst;
   a.batch = batch;
@@ -174,11 +176,11 @@ static int cell_step(const odehip_convgru_cell* c, const float* x, const float* 
                      long long nchw_batch_stride, int batch, float* gates_raw, float* z, float* rh, float* cand_raw,
                      hipStream_t stream) {
   const int H = c->hidden, I = c->input;
-  int rc = conv_layer(x, h, I, I + H, 2 * H, c->ks, c->w_gates, c->b_gates, gates_raw, 0, batch, stream, c->w_gates_bf16);
+  int rc = conv_layer(x, h, I, I + H, 2 * H, c->ks, c->w_gates, c->b_gates, gates_raw, 0, batch, stream, c->w_gates_bf16, c->w_gates_wino);
   if (rc != ODEHIP_OK) return rc;
   hipLaunchKernelGGL(gn_gates_kernel, dim3(2 * H / 32, batch), dim3(256), 0, stream, gates_raw, c->gn_gates_w, c->gn_gates_b, h, z,
                      rh, H / 32);
-  rc = conv_layer(x, rh, I, I + H, H, c->ks, c->w_can, c->b_can, cand_raw, 0, batch, stream, c->w_can_bf16);
+  rc = conv_layer(x, rh, I, I + H, H, c->ks, c->w_can, c->b_can, cand_raw, 0, batch, stream, c->w_can_bf16, c->w_can_wino);
   if (rc != ODEHIP_OK) return rc;
   hipLaunchKernelGGL(gn_update_kernel, dim3(H / 32, batch), dim3(256), 0, stream, cand_raw, c->gn_can_w, c->gn_can_b, h, z, h_out,
                      h_out_nchw, nchw_batch_stride, H / 32);

@@ -109,6 +109,7 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
                         float* out_nchw, int grid, hipStream_t stream);
 int launch_wino(const ConvArgs& a, hipStream_t stream);
+int launch_wino5(const ConvArgs& a, hipStream_t stream);  // 5x5 layers with a.w_wino (conv_wino5.hip); 1 = no such form, run the direct kernel
 int launch_bf16(const ConvArgs& a, hipStream_t stream);
 int launch_bf16_5x5(const ConvArgs& a, hipStream_t stream);
 

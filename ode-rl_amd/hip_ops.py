@@ -146,6 +146,25 @@ def pack_conv_weight_winograd(w, transpose_flip=False):
     return out
 
 
+def pack_conv_weight_winograd5(w, transpose_flip=False):
+    """(Cout,Cin,5,5) fp32 -> Winograd F(2x2,5x5) image U = G g G^T (36 values per channel pair; csrc/conv_wino5.hip)."""
+    require_device_tensor(w, "weight")
+    w = w.detach().contiguous()
+    co, ci, k, k2 = w.shape
+    if (k, k2) != (5, 5):
+        raise ValueError("this Winograd form is for 5x5 kernels")
+    if transpose_flip:
+        co, ci = ci, co
+    out = torch.empty(co * ci * 36, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().odehip_pack_conv_weight_winograd5(_ptr(w), _ptr(out), co, ci, int(bool(transpose_flip)), _stream()))
+    return out
+
+
+def winograd5_enabled():
+    """F(2x2,5x5) for the ConvGRU's fp32 5x5 convolutions: on by default, ODEHIP_WINO5=0 runs the direct kernel (A/B, tests)."""
+    return os.environ.get("ODEHIP_WINO5", "1") != "0"
+
+
 # ---- compute dtype of the 3x3 conv layers: "f32" (exact fp32 MFMA, default) or "bf16" (bf16 operands, fp32 accumulation;
 # state, stage combines and conv outputs stay fp32).  bf16 is chosen by set_compute_dtype("bf16") or, as the reference's
 # users would ask for it, by running under torch.autocast(device_type="cuda", dtype=torch.bfloat16).
@@ -572,7 +591,7 @@ class PackedCell:
     def refresh(self, mode=None):
         mode = mode or current_compute_dtype()
         ps = self._params()
-        stamp = (mode,) + tuple((p.data_ptr(), p._version) for p in ps)
+        stamp = (mode, winograd5_enabled()) + tuple((p.data_ptr(), p._version) for p in ps)
         ent = self._cache.get(mode)
         if ent is not None and ent[0] == stamp:
             self._stamp, self.desc = ent[0], ent[1]
@@ -590,7 +609,13 @@ class PackedCell:
         bf = [None, None]
         if mode == "bf16" and _bf16_cell_ok(c.input_channels, c.hidden_dim, ks):
             bf = [pack_conv_weight_bf16_ks(ps[0]), pack_conv_weight_bf16_ks(ps[4])]
+        wino = [None, None]
+        if mode == "f32" and ks == 5 and winograd5_enabled() and c.input_channels % 8 == 0 and c.hidden_dim % 32 == 0:
+            wino = [pack_conv_weight_winograd5(ps[0]), pack_conv_weight_winograd5(ps[4])]
+        keep = keep + wino
         d = _lib.ConvGRUCellDesc(input=c.input_channels, hidden=c.hidden_dim, ks=ks,
+                                 w_gates_wino=wino[0].data_ptr() if wino[0] is not None else None,
+                                 w_can_wino=wino[1].data_ptr() if wino[1] is not None else None,
                                  w_gates=keep[0].data_ptr(), b_gates=keep[1].data_ptr(), gn_gates_w=keep[2].data_ptr(),
                                  gn_gates_b=keep[3].data_ptr(), w_can=keep[4].data_ptr(), b_can=keep[5].data_ptr(),
                                  gn_can_w=keep[6].data_ptr(), gn_can_b=keep[7].data_ptr(),

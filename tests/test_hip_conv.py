@@ -106,6 +106,40 @@ def test_winograd_conv_matches_torch(cuda, b, cin, cout, relu):
     assert rel_l2(dg, xr.grad) <= 5e-6
 
 
+@pytest.mark.parametrize("b,cin1,cin2,cout,relu", [(3, 64, 64, 128, False), (2, 64, 64, 64, True), (1, 8, 0, 32, False),
+                                                   (5, 32, 32, 64, False), (2, 128, 128, 256, False), (70, 64, 64, 128, False)])
+def test_winograd5_conv_matches_torch(cuda, b, cin1, cin2, cout, relu):
+    """Winograd F(2x2,5x5) kernel (csrc/conv_wino5.hip; the ConvGRU's convolutions, two sources = torch.cat(x, h) without a copy):
+    fp32 arithmetic, reassociated through the 6-point transforms: 2.6e-6 rel-L2 per layer on the CPU model of it
+    (tools/experiments/winograd_f25_error.py); tolerance 1e-5 against torch's CPU conv2d, and the input-gradient form."""
+    from ode_rl_amd import hip_ops
+    g = torch.Generator().manual_seed(b * 131 + cin1 + cout)
+    cin = cin1 + cin2
+    x = torch.randn(b, cin, 16, 16, generator=g)
+    w = (torch.rand(cout, cin, 5, 5, generator=g) * 2 - 1) / (cin * 25) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=2)
+    if relu:
+        ref = torch.relu(ref)
+    wd = w.to(cuda)
+    src1 = hip_ops.nchw_to_q4(x[:, :cin1].contiguous().to(cuda))
+    src2 = hip_ops.nchw_to_q4(x[:, cin1:].contiguous().to(cuda)) if cin2 else None
+    out = hip_ops.q4_to_nchw(hip_ops.conv_q4(src1, hip_ops.pack_conv_weight(wd), bias.to(cuda), cout, 5, src2=src2, relu=relu,
+                                             w_wino=hip_ops.pack_conv_weight_winograd5(wd)))
+    direct = hip_ops.q4_to_nchw(hip_ops.conv_q4(src1, hip_ops.pack_conv_weight(wd), bias.to(cuda), cout, 5, src2=src2, relu=relu))
+    assert rel_l2(direct, ref) <= 2e-6
+    assert not torch.equal(out, direct)          # the Winograd kernel ran (it is not bit-identical to the direct one)
+    assert rel_l2(out, ref) <= 1e-5
+    if cin % 32 != 0 or b > 8:
+        return
+    gy = torch.randn(b, cout, 16, 16, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, padding=2).backward(gy)
+    dg = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(gy.to(cuda)), hip_ops.pack_conv_weight(wd, transpose_flip=True), None,
+                                            cin, 5, w_wino=hip_ops.pack_conv_weight_winograd5(wd, transpose_flip=True)))
+    assert rel_l2(dg, xr.grad) <= 1e-5
+
+
 @pytest.mark.parametrize("b,relu", [(3, True), (1, False)])
 def test_experimental_f43_conv_matches_torch(cuda, b, relu):
     """Winograd F(4x4,3x3) prototype (conv_f43.hip): input transform kernel + K-split matrix kernel against
