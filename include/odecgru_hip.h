@@ -248,6 +248,7 @@ typedef struct odehip_convgru_cell_bwd {
   const float* w_can_dx;       /* ... conv_can.0.weight[:, :input]                                                         */
   const float* w_can_dh;       /* ... conv_can.0.weight[:, input:]                                                         */
   const void* bf16[4];         /* optional bf16 images of the same four (odehip_pack_conv_weight_bf16_ks, transpose_flip = 1)  */
+  const float* wino[4];        /* optional F(2x2,5x5) forms of the same four (odehip_pack_conv_weight_winograd5, transpose_flip = 1) */
 } odehip_convgru_cell_bwd;
 typedef struct odehip_convgru_cell_grads {
   float *w_gates, *b_gates, *gn_gates_w, *gn_gates_b, *w_can, *b_can, *gn_can_w, *gn_can_b;
@@ -269,6 +270,7 @@ typedef struct odehip_encoder_bwd {
   const float* w_head0_t;      /* ... transform_z0.0.weight, transform_z0.2.weight                                         */
   const float* w_head1_t;
   const void* bf16[4];         /* optional bf16 images of w_gates_dx, w_gates_dh, w_can_dx, w_can_dh                          */
+  const float* wino[4];        /* optional F(2x2,5x5) forms of the same four (ks = 5, fp32 mode)                                */
 } odehip_encoder_bwd;
 
 typedef struct odehip_encoder_grads {  /* outputs, each shaped like its parameter (conv weights OIHW) */

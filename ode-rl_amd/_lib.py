@@ -59,7 +59,7 @@ class EncoderDesc(ctypes.Structure):
 
 class ConvGRUCellBwd(ctypes.Structure):
     _fields_ = [("w_gates_dx", ctypes.c_void_p), ("w_gates_dh", ctypes.c_void_p), ("w_can_dx", ctypes.c_void_p),
-                ("w_can_dh", ctypes.c_void_p), ("bf16", ctypes.c_void_p * 4)]
+                ("w_can_dh", ctypes.c_void_p), ("bf16", ctypes.c_void_p * 4), ("wino", ctypes.c_void_p * 4)]
 
 
 class ConvGRUCellGrads(ctypes.Structure):
@@ -71,7 +71,7 @@ class ConvGRUCellGrads(ctypes.Structure):
 class EncoderBwd(ctypes.Structure):
     _fields_ = [("f_dgrad", ConvStack), ("w_gates_dx", ctypes.c_void_p), ("w_gates_dh", ctypes.c_void_p),
                 ("w_can_dx", ctypes.c_void_p), ("w_can_dh", ctypes.c_void_p), ("w_head0_t", ctypes.c_void_p),
-                ("w_head1_t", ctypes.c_void_p), ("bf16", ctypes.c_void_p * 4)]
+                ("w_head1_t", ctypes.c_void_p), ("bf16", ctypes.c_void_p * 4), ("wino", ctypes.c_void_p * 4)]
 
 
 class EncoderGrads(ctypes.Structure):

@@ -197,6 +197,8 @@ __global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) 
     const char* u = smem + (c & 1) * (k5U + k5V) + frag_off;
     const char* v = u + k5U;
     if (DBG && (a.debug & 2048)) continue;
+    // (holding the last positions' second k-step back until after the next barrier, to cover the latency of the next chunk's first
+    // fragments, was measured and changes nothing: 74.7 vs 73.5 us per launch)
 #pragma unroll
     for (int n = 0; n < 9; ++n) {
       f32x2 u0, u1, v0, v1;
@@ -259,15 +261,15 @@ __global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) 
 #pragma unroll
     for (int w = 1; w < 4; ++w) y += *(const f32x4*)(px + ((w * 4 + wave) * 4 + e) * 1024 + lane * 16);
     y += bias4;
-    if (a.relu) { y.x = fmaxf(y.x, 0.0f); y.y = fmaxf(y.y, 0.0f); y.z = fmaxf(y.z, 0.0f); y.w = fmaxf(y.w, 0.0f); }
     const int P = (r0 + 2 * oty + (e >> 1)) * 16 + 2 * otx + (e & 1);
-    *(f32x4*)(a.dst + (((size_t)b * a.qout + Q) * kPix + P) * 4) = y;
+    float esum = 0.0f;
+    emit_quad(a, b, Q, P, y, esum);  // plain / ReLU store, or the backward sweep's epilogues (conv_common.h)
   }
 }
 
 // returns 1 if the layer has no F(2x2,5x5) form here (the caller then runs the direct kernel)
 int launch_wino5(const ConvArgs& a, hipStream_t stream) {
-  if (a.combine != 0 || a.skip || (a.q1 & 1) || (a.qin & 1)) return 1;
+  if (a.combine == 1 || a.skip || (a.q1 & 1) || (a.qin & 1)) return 1;  // (no Runge-Kutta stage combine on a 5x5 layer)
   static bool attr_set = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv5x5_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -416,7 +416,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
   const size_t pgg_half = (size_t)T * batch * 2 * C, pgc_half = (size_t)T * batch * C;
 
   auto conv_bwd = [&](const float* src, int cin, int cout, int k, const float* wt, int combine, const BwdArgs* bw, float* dst,
-                      const void* wbf = nullptr) {
+                      const void* wbf = nullptr, const float* wwino = nullptr) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src1 = src;
@@ -424,6 +424,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
     a.qout = cout / 4;
     a.w_packed = wt;
     a.w_bf16 = wbf;
+    a.w_wino = wbf ? nullptr : wwino;
     a.batch = batch;
     a.combine = combine;
     if (bw) a.bwd = *bw;
@@ -453,8 +454,8 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
     hipLaunchKernelGGL(gn_update_bwd_kernel, dim3(HG, batch), dim3(256), 0, stream, L.per(ws, L.off_cand, idx, L.hs), e->cell.gn_can_w,
                        e->cell.gn_can_b, gh, L.per(ws, L.off_z, idx, L.hs), h_ode, g_cand, gz_pre, gh_ode,
                        pgc + (size_t)idx * batch * C, pgc + pgc_half + (size_t)idx * batch * C, HG);
-    if ((rc = conv_bwd(g_cand, C, C, ks, eb->w_can_dx, 0, nullptr, gx_c, eb->bf16[2])) != ODEHIP_OK) return rc;
-    if ((rc = conv_bwd(g_cand, C, C, ks, eb->w_can_dh, 0, nullptr, g_rh, eb->bf16[3])) != ODEHIP_OK) return rc;
+    if ((rc = conv_bwd(g_cand, C, C, ks, eb->w_can_dx, 0, nullptr, gx_c, eb->bf16[2], eb->wino[2])) != ODEHIP_OK) return rc;
+    if ((rc = conv_bwd(g_cand, C, C, ks, eb->w_can_dh, 0, nullptr, g_rh, eb->bf16[3], eb->wino[3])) != ODEHIP_OK) return rc;
     hipLaunchKernelGGL(gn_gates_bwd_kernel, dim3(2 * HG, batch), dim3(256), 0, stream, L.per(ws, L.off_gates, idx, 2 * L.hs),
                        e->cell.gn_gates_w, e->cell.gn_gates_b, gz_pre, g_rh, h_ode, gh_ode, g_gates,
                        pgg + (size_t)idx * batch * 2 * C, pgg + pgg_half + (size_t)idx * batch * 2 * C, HG);
@@ -465,10 +466,10 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
     w.tgt[0].srcA = gx_c;
     w.tgt[0].a_c = 1.0f;
     w.tgt[0].g_c = 1.0f;
-    if ((rc = conv_bwd(g_gates, 2 * C, C, ks, eb->w_gates_dx, 3, &w, nullptr, eb->bf16[0])) != ODEHIP_OK) return rc;
+    if ((rc = conv_bwd(g_gates, 2 * C, C, ks, eb->w_gates_dx, 3, &w, nullptr, eb->bf16[0], eb->wino[0])) != ODEHIP_OK) return rc;
     w.tgt[0].out = L.gp(ws, idx, NH);             // seed of the encoder-dynamics chain = total gradient of h_ode
     w.tgt[0].srcA = gh_ode;
-    if ((rc = conv_bwd(g_gates, 2 * C, C, ks, eb->w_gates_dh, 3, &w, nullptr, eb->bf16[1])) != ODEHIP_OK) return rc;
+    if ((rc = conv_bwd(g_gates, 2 * C, C, ks, eb->w_gates_dh, 3, &w, nullptr, eb->bf16[1], eb->wino[1])) != ODEHIP_OK) return rc;
     // h_ode = h + dt f(h):  gh = seed + dt J_f(h)^T seed
     {
       float* gpv[ODEHIP_MAX_LAYERS];
@@ -619,7 +620,8 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
   if ((rc = odehip_nchw_to_q4(grad_h_next_nchw, ghn, batch, H, stream)) != ODEHIP_OK) return rc;
   if ((rc = cell_step_q4(c, x, h, hn, nullptr, 0, batch, gates, z, rh, cand, stream)) != ODEHIP_OK) return rc;
 
-  auto conv_bwd = [&](const float* src, int cin, int cout, const float* wt, const BwdArgs* bw, float* dst, const void* wbf) {
+  auto conv_bwd = [&](const float* src, int cin, int cout, const float* wt, const BwdArgs* bw, float* dst, const void* wbf,
+                      const float* wwino) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.src1 = src;
@@ -627,6 +629,7 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
     a.qout = cout / 4;
     a.w_packed = wt;
     a.w_bf16 = wbf;
+    a.w_wino = wbf ? nullptr : wwino;
     a.batch = batch;
     a.combine = bw ? 3 : 0;
     if (bw) a.bwd = *bw;
@@ -635,8 +638,8 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
   };
   hipLaunchKernelGGL(gn_update_bwd_kernel, dim3(HG, batch), dim3(256), 0, stream, cand, c->gn_can_w, c->gn_can_b, ghn, z, h, g_cand,
                      gz_pre, gh_ode, pgc, pgc + (size_t)batch * H, HG);
-  if ((rc = conv_bwd(g_cand, H, I, cb->w_can_dx, nullptr, gx_c, cb->bf16[2])) != ODEHIP_OK) return rc;
-  if ((rc = conv_bwd(g_cand, H, H, cb->w_can_dh, nullptr, g_rh, cb->bf16[3])) != ODEHIP_OK) return rc;
+  if ((rc = conv_bwd(g_cand, H, I, cb->w_can_dx, nullptr, gx_c, cb->bf16[2], cb->wino[2])) != ODEHIP_OK) return rc;
+  if ((rc = conv_bwd(g_cand, H, H, cb->w_can_dh, nullptr, g_rh, cb->bf16[3], cb->wino[3])) != ODEHIP_OK) return rc;
   hipLaunchKernelGGL(gn_gates_bwd_kernel, dim3(2 * HG, batch), dim3(256), 0, stream, gates, c->gn_gates_w, c->gn_gates_b, gz_pre, g_rh, h,
                      gh_ode, g_gates, pgg, pgg + (size_t)batch * 2 * H, HG);
   BwdArgs w;
@@ -646,10 +649,10 @@ extern "C" int odehip_convgru_cell_backward(const odehip_convgru_cell* c, const 
   w.tgt[0].srcA = gx_c;
   w.tgt[0].a_c = 1.0f;
   w.tgt[0].g_c = 1.0f;
-  if ((rc = conv_bwd(g_gates, 2 * H, I, cb->w_gates_dx, &w, nullptr, cb->bf16[0])) != ODEHIP_OK) return rc;
+  if ((rc = conv_bwd(g_gates, 2 * H, I, cb->w_gates_dx, &w, nullptr, cb->bf16[0], cb->wino[0])) != ODEHIP_OK) return rc;
   w.tgt[0].out = gh;
   w.tgt[0].srcA = gh_ode;
-  if ((rc = conv_bwd(g_gates, 2 * H, H, cb->w_gates_dh, &w, nullptr, cb->bf16[1])) != ODEHIP_OK) return rc;
+  if ((rc = conv_bwd(g_gates, 2 * H, H, cb->w_gates_dh, &w, nullptr, cb->bf16[1], cb->wino[1])) != ODEHIP_OK) return rc;
   if ((rc = odehip_q4_to_nchw(gx_out, grad_x_nchw, batch, I, stream)) != ODEHIP_OK) return rc;
   if ((rc = odehip_q4_to_nchw(gh, grad_h_nchw, batch, H, stream)) != ODEHIP_OK) return rc;
 

@@ -635,7 +635,10 @@ def _cell_bwd_packs(cell, d, mode):
     bf = [None] * 4
     if mode == "bf16" and d.ks == 5 and all(w.shape[0] <= 128 and w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0 for w in slices):
         bf = [pack_conv_weight_bf16_ks(w, True) for w in slices]
-    return keep, bf
+    wino = [None] * 4
+    if mode == "f32" and d.ks == 5 and winograd5_enabled() and all(w.shape[0] % 8 == 0 and w.shape[1] % 32 == 0 for w in slices):
+        wino = [pack_conv_weight_winograd5(w, True) for w in slices]
+    return keep, bf, wino
 
 
 def convgru_cell_forward(packed_cell, x, h):
@@ -661,11 +664,12 @@ def convgru_cell_backward(packed_cell, x, h, grad_h_next):
     d = packed_cell.refresh()
     cached = getattr(packed_cell, "_bwd", None)
     if cached is None or cached[0] != packed_cell._stamp:
-        keep, bf = _cell_bwd_packs(packed_cell.cell, d, current_compute_dtype())
+        keep, bf, wino = _cell_bwd_packs(packed_cell.cell, d, current_compute_dtype())
         bw = _lib.ConvGRUCellBwd(*[k.data_ptr() for k in keep])
         for j in range(4):
             bw.bf16[j] = bf[j].data_ptr() if bf[j] is not None else None
-        cached = packed_cell._bwd = (packed_cell._stamp, bw, keep, bf)
+            bw.wino[j] = wino[j].data_ptr() if wino[j] is not None else None
+        cached = packed_cell._bwd = (packed_cell._stamp, bw, keep, bf, wino)
     bw = cached[1]
     x, h, grad_h_next = x.contiguous(), h.contiguous(), grad_h_next.contiguous()
     b = x.shape[0]
@@ -729,14 +733,15 @@ def _encoder_bwd_desc(enc):
     cached = getattr(enc, "_bwd", None)
     if cached is not None and cached[0] is stamp:
         return cached[1]
-    keep, bf = _cell_bwd_packs(enc.packed_cell.cell, d.cell, current_compute_dtype())
+    keep, bf, wino = _cell_bwd_packs(enc.packed_cell.cell, d.cell, current_compute_dtype())
     keep += [pack_conv_weight(enc.head[0].weight, True), pack_conv_weight(enc.head[2].weight, True)]
     b = _lib.EncoderBwd()
     b.f_dgrad = enc.f_stack.dgrad_desc()
     b.w_gates_dx, b.w_gates_dh, b.w_can_dx, b.w_can_dh, b.w_head0_t, b.w_head1_t = (k.data_ptr() for k in keep)
     for j in range(4):
         b.bf16[j] = bf[j].data_ptr() if bf[j] is not None else None
-    keep = keep + bf
+        b.wino[j] = wino[j].data_ptr() if wino[j] is not None else None
+    keep = keep + bf + wino
     enc._bwd = (stamp, b, keep)
     return b
 
