@@ -197,8 +197,9 @@ __global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) 
     const char* u = smem + (c & 1) * (k5U + k5V) + frag_off;
     const char* v = u + k5U;
     if (DBG && (a.debug & 2048)) continue;
-    // (holding the last positions' second k-step back until after the next barrier, to cover the latency of the next chunk's first
-    // fragments, was measured and changes nothing: 74.7 vs 73.5 us per launch)
+    // (measured and dropped, same microbenchmark: holding the last positions' second k-step back until after the next barrier to
+    // cover the latency of the next chunk's first fragments: 74.7 vs 73.5 us per launch; forcing both k-steps of a position to issue
+    // together so that fragments are consumed at the rate the LDS delivers them: 76.0 vs 73.5 us)
 #pragma unroll
     for (int n = 0; n < 9; ++n) {
       f32x2 u0, u1, v0, v1;
