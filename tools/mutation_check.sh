@@ -10,8 +10,12 @@ declare -A SED
 SED[rk4_stage3]='s/c.c1\[0\] = -third;/c.c1[0] = -0.25f;/'                                   # x3 = y + h (k2 - k1/3): -1/3 -> -1/4
 SED[rk4_weights_classic]='s/c.c2\[0\] = 0.125f;/c.c2[0] = 0.1666667f;/;s/c.c2\[3\] = 0.125f;/c.c2[3] = 0.1666667f;/;s/c.c2\[1\] = 0.375f;/c.c2[1] = 0.3333333f;/;s/c.c2\[2\] = 0.375f;/c.c2[2] = 0.3333333f;/'
 SED[midpoint_half]='s/c.c1\[0\] = 0.5f;/c.c1[0] = 0.45f;/'
+SED[codec_convt_tap]='s/if (parity == 0) { k = t == 0 ? 1 : 3;/if (parity == 0) { k = t == 0 ? 3 : 1;/'        # frame decoder: kernel rows of the even output rows swapped
+SED[codec_enc_slope]='s/v = w2\[((size_t)co \* kEncMid + 4 \* kq + j) \* 9 + tap\];/v = w2[((size_t)co * kEncMid + 4 * kq + j) * 9 + (8 - tap)];/'  # frame encoder: second conv's filter flipped
+SED[wino5_bt_coef]='s/out\[0\] = fma2(4.0f, in\[0\], fma2(-5.0f, in\[2\], in\[4\]));/out[0] = fma2(4.0f, in[0], fma2(-4.0f, in[2], in[4]));/'      # F(2x2,5x5): B^T row 0: -5 -> -4
+SED[wino5_at_coef]='s/(i == 3 ? 2.0f : (i == 4 ? -2.0f : 1.0f))/(i == 3 ? 2.0f : (i == 4 ? -1.0f : 1.0f))/'    # F(2x2,5x5): A^T row 1: -2 -> -1
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle"
+TESTS="tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
@@ -19,10 +23,12 @@ build)
     rm -rf "$d"; mkdir -p "$d/ode-rl_amd/csrc" "$d/include"
     cp "$ROOT"/ode-rl_amd/csrc/*.hip "$ROOT"/ode-rl_amd/csrc/*.h "$ROOT"/ode-rl_amd/csrc/Makefile "$d/ode-rl_amd/csrc/"
     cp "$ROOT"/include/*.h "$d/include/"
-    sed -i "${SED[$m]}" "$d/ode-rl_amd/csrc/fixed_grid.hip" "$d/ode-rl_amd/csrc/odehip_internal.h"
-    if diff -q "$d/ode-rl_amd/csrc/fixed_grid.hip" "$ROOT/ode-rl_amd/csrc/fixed_grid.hip" >/dev/null && diff -q "$d/ode-rl_amd/csrc/odehip_internal.h" "$ROOT/ode-rl_amd/csrc/odehip_internal.h" >/dev/null; then
-      echo "mutant $m: the pattern matched nothing" >&2; exit 1
-    fi
+    sed -i "${SED[$m]}" "$d"/ode-rl_amd/csrc/*.hip "$d"/ode-rl_amd/csrc/*.h
+    changed=0
+    for f in "$d"/ode-rl_amd/csrc/*.hip "$d"/ode-rl_amd/csrc/*.h; do
+      diff -q "$f" "$ROOT/ode-rl_amd/csrc/$(basename "$f")" >/dev/null || changed=$((changed + 1))
+    done
+    if [ $changed -ne 1 ]; then echo "mutant $m: the pattern changed $changed files (expected exactly 1)" >&2; exit 1; fi
     make -s -C "$d/ode-rl_amd/csrc" -j8 OUT_DIR="$d/lib" >/dev/null 2>&1 || { echo "mutant $m failed to build" >&2; exit 1; }
     rm -rf "$d/ode-rl_amd/csrc/build"
     echo "built $m"
