@@ -8,7 +8,7 @@ cd $ROOT
 run() { name=$1; shift; timeout -k 10 280 python3 bench.py "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "$name FAILED"; python3 - $OUT/$name.json $name <<'PY'
 import json, sys
 try:
-    d = json.load(open(sys.argv[1]))
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])   # (gloo prints a connection line to stdout in the rehearsal mode)
     t = d.get("train") or {}
     print(f"{sys.argv[2]:28s} {d['ms_per_step']:8.3f} ms  median {d['median_ms_per_step']:8.3f}  {d['value']:10.0f} frames/s  frac {d['roofline']['frac']:.3f}  kernel {d['roofline']['kernel'][:40]}  train-leg {t.get('ms_per_step')}")
 except Exception as e:
