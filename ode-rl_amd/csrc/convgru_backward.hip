@@ -296,7 +296,7 @@ struct EncLayout {
     off_pgg = take((size_t)2 * T * B * 2 * C * 4);
     off_pgc = take((size_t)2 * T * B * C * 4);
     off_tab = take((size_t)T * sizeof(WgradPair));
-    off_slab = take((size_t)B * 4 * (64 * 64 * 10 + 64) * 4);
+    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
     total = o;
   }
   float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }
@@ -582,7 +582,7 @@ struct CellBwdLayout {
     g_cand = take(hs); g_gates = take(2 * hs); gz_pre = take(hs); gh_ode = take(hs); g_rh = take(hs); gh = take(hs);
     pg = take((size_t)6 * batch * c->hidden * 4);  // [dgamma_g | dbeta_g] (2H each) then [dgamma_c | dbeta_c] (H each), per sample
     table = take(sizeof(WgradPair));
-    slabs = take((size_t)batch * 4 * (64 * 64 * 10 + 64) * 4);
+    slabs = take(((size_t)batch * 4 + 1) * kWgradSlabFloats * 4);
     total = o;
   }
 };

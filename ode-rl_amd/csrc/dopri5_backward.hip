@@ -67,7 +67,7 @@ struct BwdLayout {
     off_gk1 = take(2 * st);
     off_slots = take((size_t)(N > 0 ? N : 1) * slot_bytes);
     off_tab = take(((size_t)N * 6 + 1) * sizeof(WgradPair));
-    off_slab = take((size_t)B * 4 * (64 * 64 * 9 + 64) * 4);
+    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
     total = o;
   }
   float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }

@@ -59,7 +59,7 @@ struct FixedLayout {
       off_gy = take(st);
       off_g2 = take(2 * st);
       off_tab = take(ne * sizeof(WgradPair));
-      off_slab = take((size_t)B * kEsplit * (64 * 64 * 9 + 64) * 4);
+      off_slab = take(((size_t)B * kEsplit + 1) * kWgradSlabFloats * 4);
     }
     total = o;
   }

@@ -162,6 +162,11 @@ struct WgradPair {
   float pad_[3];
 };
 // bf16 = true: operands rounded to bf16 (fp32 accumulation), for stacks running in bf16 compute mode
+// floats per workgroup slab of the weight-gradient kernels: the Winograd-domain tile [16 positions][64][64] + 64 bias sums is the
+// largest; every slab region holds batch * esplit of them PLUS ONE (the fixed-order sum before the final G^T . G)
+constexpr int kWgradSlabFloats = 16 * 64 * 64 + 64;
+int launch_wgrad_wino(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                      int cin, hipStream_t stream);  // wgrad_wino.hip; 1 = switched off
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                  int cin, hipStream_t stream, bool bf16 = false);
 int launch_wgrad_q4h(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, int accumulate,

@@ -361,6 +361,10 @@ int launch_wgrad_bf16(const WgradPair* table_dev, int n_eval, int batch, int esp
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                  int cin, hipStream_t stream, bool bf16) {
   if (bf16) return launch_wgrad_bf16(table_dev, n_eval, batch, esplit, slabs, dw, db, cout, cin, stream);
+  {  // fp32: the Winograd-domain kernel (2.25x fewer multiplies, wgrad_wino.hip) unless switched off
+    const int rw = launch_wgrad_wino(table_dev, n_eval, batch, esplit, slabs, dw, db, cout, cin, stream);
+    if (rw != 1) return rw;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -1,0 +1,246 @@
+// wgrad_wino.hip -- weight gradient of the 3x3 layers of f in the Winograd F(2x2,3x3) domain (gfx950, exact fp32 MFMA).
+//
+//   dg[co][ci] = G^T [ sum over evaluations e, samples b, tiles  (A dY A^T)[co] .* (B^T d B)[ci] ] G
+// (dY: the gradient w.r.t. the layer's output, d: the layer's saved input, both Q4; tools/experiments/winograd_wgrad_check.py:
+// identity 1e-15 in fp64, fp32 error 4.9e-7 rel-L2 against 5.5e-7 for the direct sum).  Y is linear in g, so the 16 multiplies of
+// the forward tile become 16 multiplies of the gradient tile: 2.25x fewer than the 36 of the direct sum (wgrad64_kernel), and the
+// contraction index is the TILE (64 per sample) instead of the pixel.  Same contract as wgrad64_kernel: one launch per layer and
+// 64x64 channel tile, workgroup (sample b, split s) walks its share of the evaluations and keeps the whole gradient tile -- here
+// 16 positions x 64 x 64 -- in MFMA accumulators (8 waves x 128 VGPRs); one slab per workgroup at the end, summed in a fixed order
+// (bitwise reproducible, no float atomics), then G^T . G per channel pair.
+//
+// Per chunk of 16 tiles (two tile rows): every thread transforms ONE (tile, channel quad) of ONE operand -- waves 0-3 the gradient
+// (4 loads, W = A dY A^T, bias sums), waves 4-7 the activations (16 zero-padded buffer loads, V = B^T d B) -- into LDS
+// ([xi 16][tile 16][quad 16] x 16 B per operand, quads XOR-swizzled by the tile so that the MFMA fragment reads are conflict-free),
+// then wave w multiplies positions xi = 2w, 2w+1: 4 K-steps x (4 + 4 ds_read_b32) feed 128 v_mfma_f32_16x16x4_f32.  The loads of
+// the next chunk are issued before the MFMAs of the current one.
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace odehip {
+
+constexpr int kWwPlane = 16 * 16 * 16;        // one position of one operand: [tile 16][quad 16] x 16 B
+constexpr int kWwOperand = 16 * kWwPlane;     // 64 KiB
+constexpr int kWwLds = 2 * kWwOperand;        // W | V
+
+__device__ __forceinline__ f32x4 bufload(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+// The whole walk of one wave; ACT = false: this wave transforms gradients (W = A dY A^T, bias sums), true: activations (V = B^T d B).
+// Both instantiations execute the same barriers and the same multiply phase.
+template <bool ACT>
+__device__ __forceinline__ void wgrad_wino_walk(const WgradPair* __restrict__ table, int n_eval, int esplit, float* __restrict__ slabs,
+                                                int g_quad0, int g_quads, int a_quad0, int a_quads, char* smem, int lane, int wave, int dbg) {
+  const int b = blockIdx.x, es = blockIdx.y;
+  // ---- transform role: channel quad, tile within the chunk.  Quads are XOR-swizzled by the tile ((tile & 3) into the upper, tile >> 2
+  // into the lower two bits): the 64 b128 writes of a wave and the 64 b32 fragment reads of a K-step both spread evenly over the banks.
+  const int quad = 4 * (wave & 3) + (lane >> 4);
+  const int tl = lane & 15, tyl = tl >> 3, tx = tl & 7;
+  char* const wr = smem + (ACT ? kWwOperand : 0) + tl * 256 + ((quad ^ ((tl & 3) << 2) ^ (tl >> 2)) * 16);  // + xi * kWwPlane
+  // ---- multiply role: positions 2 wave, 2 wave + 1; lane (m, kq)
+  const int m = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[x][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  const int n_mine = es < n_eval ? (n_eval - es + esplit - 1) / esplit : 0;
+  const int n_it = n_mine * 4;  // (evaluation, chunk) pairs
+  constexpr int NR = ACT ? 16 : 4;
+  f32x4 raw[NR];
+  float esc_raw = 0.0f;
+  auto issue = [&](int it) {  // the global loads of (evaluation, chunk) `it` into raw
+    const int e = es + (it >> 2) * esplit, c = it & 3;
+    const WgradPair pr = table[e];
+    esc_raw = pr.scale;
+    const int ty = 2 * c + tyl;
+    if (!ACT) {
+      const __amdgpu_buffer_rsrc_t rg = make_rsrc(pr.g + ((size_t)b * g_quads + g_quad0) * 4 * kPix, 64 * kPix * 4);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) raw[(2 * k + l) % NR] = bufload(rg, quad * 4096 + ((2 * ty + k) * 16 + 2 * tx + l) * 16);
+    } else {
+      const __amdgpu_buffer_rsrc_t ra = make_rsrc(pr.a + ((size_t)b * a_quads + a_quad0) * 4 * kPix, 64 * kPix * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const int row = 2 * ty - 1 + k, col = 2 * tx - 1 + l;
+          const bool in = row >= 0 && row < kHW && col >= 0 && col < kHW;
+          raw[(4 * k + l) % NR] = bufload(ra, in ? quad * 4096 + (row * 16 + col) * 16 : kOobOffset);  // out of range: zeros
+        }
+    }
+  };
+  auto transform = [&]() {  // raw -> this thread's 16 positions in LDS
+    if (!ACT) {
+      const f32x4 d00 = raw[0] * esc_raw, d01 = raw[1 % NR] * esc_raw, d10 = raw[2 % NR] * esc_raw, d11 = raw[3 % NR] * esc_raw;
+      bsum += (d00 + d01) + (d10 + d11);
+      // t = A dY (4x2), W = t A^T: rows [t0, t0 + t1, t0 - t1, -t1]
+      const f32x4 t[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(f32x4*)(wr + (4 * i + 0) * kWwPlane) = t[i][0];
+        *(f32x4*)(wr + (4 * i + 1) * kWwPlane) = t[i][0] + t[i][1];
+        *(f32x4*)(wr + (4 * i + 2) * kWwPlane) = t[i][0] - t[i][1];
+        *(f32x4*)(wr + (4 * i + 3) * kWwPlane) = -t[i][1];
+      }
+    } else {
+      // T = B^T d row by row (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]), V = T B
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 T[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const f32x4 r0 = raw[l % NR], r1 = raw[(4 + l) % NR], r2 = raw[(8 + l) % NR], r3 = raw[(12 + l) % NR];
+          T[l] = i == 0 ? r0 - r2 : (i == 1 ? r1 + r2 : (i == 2 ? r2 - r1 : r1 - r3));
+        }
+        *(f32x4*)(wr + (4 * i + 0) * kWwPlane) = T[0] - T[2];
+        *(f32x4*)(wr + (4 * i + 1) * kWwPlane) = T[1] + T[2];
+        *(f32x4*)(wr + (4 * i + 2) * kWwPlane) = T[2] - T[1];
+        *(f32x4*)(wr + (4 * i + 3) * kWwPlane) = T[1] - T[3];
+      }
+    }
+  };
+
+  if (n_it > 0) issue(0);
+#pragma unroll 1
+  for (int it = 0; it < n_it; ++it) {
+    if (!(dbg & 1)) transform();
+    __builtin_amdgcn_s_barrier();  // W and V of this chunk are in LDS
+    if (it + 1 < n_it && !(dbg & 4)) issue(it + 1);
+    if (dbg & 2) { __builtin_amdgcn_s_barrier(); continue; }
+    // fragment of K-step s: tile 4 s + kq, channel 16 blk + m  ->  quad (4 blk + m / 4) ^ (kq << 2) ^ s, float m % 4
+    const char* fw = smem + (2 * wave) * kWwPlane + kq * 256 + (m & 3) * 4;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float af[4], bf[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          const int off = x * kWwPlane + s * 1024 + (((4 * blk + (m >> 2)) ^ (kq << 2) ^ s) * 16);
+          af[blk] = *(const float*)(fw + off);
+          bf[blk] = *(const float*)(fw + kWwOperand + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[x][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[x][i][j], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_barrier();  // every wave is done reading before the next chunk is written
+  }
+
+  // slab[(b * esplit + es)] = dU [xi 16][co 64][ci 64] followed by db (64)
+  float* slab = slabs + (size_t)(b * esplit + es) * kWgradSlabFloats;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // D row = 4 kq + r -> co, D col = m -> ci
+          slab[((size_t)(2 * wave + x) * 64 + 16 * i + 4 * kq + r) * 64 + 16 * j + m] = acc[x][i][j][r];
+  if (!ACT) {  // this lane's bias sums cover its tiles of channel quad `quad`: fold the 16 tile lanes
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (tl == 0) slab[16 * 64 * 64 + 4 * quad + c] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                              float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                              int a_quads, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) wgrad_wino_walk<false>(table, n_eval, esplit, slabs, g_quad0, g_quads, a_quad0, a_quads, smem, lane, wave, dbg);
+  else          wgrad_wino_walk<true>(table, n_eval, esplit, slabs, g_quad0, g_quads, a_quad0, a_quads, smem, lane, wave, dbg);
+}
+
+// sum[i] = sum over slabs in a fixed order (the pattern of wgrad_reduce_kernel)
+__global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(const float* __restrict__ slabs, int n_slabs, float* __restrict__ sum) {
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+  if (i < kWgradSlabFloats) {
+    for (int k = g; k < n_slabs; k += 16) {
+      p0 += slabs[(size_t)k * kWgradSlabFloats + i];
+      if (k + 4 < n_slabs) p1 += slabs[(size_t)(k + 4) * kWgradSlabFloats + i];
+      if (k + 8 < n_slabs) p2 += slabs[(size_t)(k + 8) * kWgradSlabFloats + i];
+      if (k + 12 < n_slabs) p3 += slabs[(size_t)(k + 12) * kWgradSlabFloats + i];
+    }
+  }
+  part[g][o] = (p0 + p1) + (p2 + p3);
+  __syncthreads();
+  if (g == 0 && i < kWgradSlabFloats) sum[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+}
+
+// dg = G^T dU G per channel pair (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]); the 64x64 tile lands at (co0, ci0) of the
+// (cout, cin, 3, 3) gradient, db (only for ci0 == 0) at co0
+__global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ sum, float* __restrict__ dw, float* __restrict__ db,
+                                                                int cin, int co0, int ci0) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // co * 64 + ci
+  const int co = idx >> 6, ci = idx & 63;
+  float u[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[i][j] = sum[(size_t)(4 * i + j) * 4096 + idx];
+  float R[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float hs = 0.5f * (u[1][j] + u[2][j]), hd = 0.5f * (u[1][j] - u[2][j]);
+    R[0][j] = u[0][j] + hs;
+    R[1][j] = hd;
+    R[2][j] = hs + u[3][j];
+  }
+  float* o = dw + ((size_t)(co0 + co) * cin + ci0 + ci) * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float hs = 0.5f * (R[a][1] + R[a][2]), hd = 0.5f * (R[a][1] - R[a][2]);
+    o[3 * a + 0] = R[a][0] + hs;
+    o[3 * a + 1] = hd;
+    o[3 * a + 2] = hs + R[a][3];
+  }
+  if (ci == 0 && ci0 == 0) db[co0 + co] = sum[16 * 64 * 64 + co];
+}
+
+// the fp32 3x3 weight gradient of launch_wgrad (wgrad.hip); returns 1 if switched off (ODEHIP_WGRAD_WINO=0: the direct kernel)
+int launch_wgrad_wino(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
+                      int cin, hipStream_t stream) {
+  static const bool off = [] { const char* e = getenv("ODEHIP_WGRAD_WINO"); return e && e[0] == '0'; }();
+  if (off) return 1;
+  static const int dbg = [] { const char* e = getenv("ODEHIP_WW_DBG"); return e ? atoi(e) : 0; }();  // ablations (timing only)
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  float* const sum = slabs + (size_t)batch * esplit * kWgradSlabFloats;  // the slab region is sized for one more slab
+  for (int co0 = 0; co0 < cout; co0 += 64)
+    for (int ci0 = 0; ci0 < cin; ci0 += 64) {
+      hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(batch, esplit), dim3(512), kWwLds, stream, table_dev, n_eval, esplit, slabs, co0 / 4,
+                         cout / 4, ci0 / 4, cin / 4, dbg);
+      hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((kWgradSlabFloats + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sum);
+      hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(16), dim3(256), 0, stream, sum, dw, db, cin, co0, ci0);
+    }
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+}  // namespace odehip
