@@ -14,8 +14,10 @@ SED[codec_convt_tap]='s/if (parity == 0) { k = t == 0 ? 1 : 3;/if (parity == 0) 
 SED[codec_enc_slope]='s/v = w2\[((size_t)co \* kEncMid + 4 \* kq + j) \* 9 + tap\];/v = w2[((size_t)co * kEncMid + 4 * kq + j) * 9 + (8 - tap)];/'  # frame encoder: second conv's filter flipped
 SED[wino5_bt_coef]='s/out\[0\] = fma2(4.0f, in\[0\], fma2(-5.0f, in\[2\], in\[4\]));/out[0] = fma2(4.0f, in[0], fma2(-4.0f, in[2], in[4]));/'      # F(2x2,5x5): B^T row 0: -5 -> -4
 SED[wino5_at_coef]='s/(i == 3 ? 2.0f : (i == 4 ? -2.0f : 1.0f))/(i == 3 ? 2.0f : (i == 4 ? -1.0f : 1.0f))/'    # F(2x2,5x5): A^T row 1: -2 -> -1
+SED[wgrad_wino_g]='s/const float hs = 0.5f \* (u\[1\]\[j\] + u\[2\]\[j\]), hd = 0.5f \* (u\[1\]\[j\] - u\[2\]\[j\]);/const float hs = 0.5f * (u[1][j] + u[2][j]), hd = 0.4f * (u[1][j] - u[2][j]);/'   # Winograd-domain weight gradient: one G entry 0.5 -> 0.4
+SED[wgrad_wino_at]='s/\*(f32x4\*)(wr + (4 \* i + 2) \* kWwPlane) = t\[i\]\[0\] - t\[i\]\[1\];/*(f32x4*)(wr + (4 * i + 2) * kWwPlane) = t[i][0] + t[i][1];/'   # ... and one sign of A dY A^T
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle"
+TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
