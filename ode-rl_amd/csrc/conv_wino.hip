@@ -56,6 +56,7 @@ struct PersistHook {
   int batch;
   unsigned abort_tag;  // value of *abort_ that means "this launch has given up" (epoch + 1)
   bool first;          // layer 0 of the launch: its input was complete before the launch
+  bool solo;           // the group walks ONE sample: the producers have nothing to prepare while the consumers finish a layer
 };
 __device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
   if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
@@ -202,7 +203,18 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       // chunks 0 and 1 are the channels of co tile 0: only ITS two workgroups must be done before they are loaded; co tile 1's are
       // waited for in front of chunk 2 (same-box A/B over 10 alternations: median 1.4152 -> 1.4076 ms per trajectory; a wait per
       // chunk -- four polls per layer -- costs more than it saves: 1.53 ms)
-      if (!hk.first) wait_done(hk, 0x8, 0x0);
+      if (!hk.first) {
+        // One sample per group: the partners cannot be done before this workgroup's own consumers are through their last chunk (~1 us
+        // from here): sleep through most of it instead of polling -- a polling wave takes issue slots from the consumer wave of its
+        // SIMD.  Same-box A/B, 6-8 alternations each: 0.37 us of sleep +0.5 %, 0.55 us -2 %, 0.75 us (this) -2.5 .. -4 %, 0.9 us the
+        // same, 1.1 us -2 %, 1.5 us +1 % (the flags are then seen late); a barrier that releases the producers exactly when the
+        // consumers' last MFMA has issued is worse than the fixed sleep (it also holds back the next layer's first weight chunk).
+        if (hk.solo) {
+          __builtin_amdgcn_s_sleep(12);
+          __builtin_amdgcn_s_sleep(12);
+        }
+        wait_done(hk, 0x8, 0x0);
+      }
       if (pw == 0) pstamp(hk, 1, lane);
       issue_raw(0, 0);
       issue_raw(1, 1);
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -536,7 +548,7 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
-                                pa.epoch + 1u, l == 0};
+                                pa.epoch + 1u, l == 0, n_interleaved == 1};
         wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
       }
       src = src_next;
