@@ -57,6 +57,8 @@ struct PersistHook {
   unsigned abort_tag;  // value of *abort_ that means "this launch has given up" (epoch + 1)
   bool first;          // layer 0 of the launch: its input was complete before the launch
   bool solo;           // the group walks ONE sample: the producers have nothing to prepare while the consumers finish a layer
+  bool announce;       // false: the first of a workgroup's two passes over a 128-channel layer -- its flags are stored after the second
+  bool split_wait;     // the input chunks 0/1 and 2/3 come from the two co tiles of a 64 -> 64 layer: wait for them separately
 };
 __device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
   if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
@@ -95,7 +97,9 @@ __device__ __forceinline__ void wait_done(const PersistHook& hk, int sel_mask = 
 // One 3x3 layer for workgroup (sample b, 32-channel tile ct, image half rh).  PERSIST: called in a loop by
 // wino_persist_kernel -- the input tile is loaded past the per-CU cache (sc0 sc1: it was written by other CUs of this launch),
 // the first weight chunk is requested BEFORE waiting for the partners, and finished output is announced through hk.done.
-template <int NCHUNK, bool DBG, bool PERSIST>
+// QOUT: output channel quads of the layer as the PERSIST epilogue's prefetched operands are addressed (16 = 64 channels; the
+// per-launch kernel goes through emit_quad, which reads a.qout)
+template <int NCHUNK, bool DBG, bool PERSIST, int QOUT = 16>
 __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, const float* __restrict__ p_u, int p_qin, const ConvArgs& a,
                                            int b, int ct, int rh, char* smem, const PersistHook& hk) {
   static_assert(!PERSIST || (NCHUNK % 2 == 0), "the layer-to-layer LDS hand-over assumes an even chunk count");
@@ -213,7 +217,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
           __builtin_amdgcn_s_sleep(12);
           __builtin_amdgcn_s_sleep(12);
         }
-        wait_done(hk, 0x8, 0x0);
+        if (hk.split_wait) wait_done(hk, 0x8, 0x0); else wait_done(hk);
       }
       if (pw == 0) pstamp(hk, 1, lane);
       issue_raw(0, 0);
@@ -237,7 +241,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       if (!skip && !dbg_noprod && c + 1 < nchunk) {
         if (!dbg_nodma) issue_u(c + 1, (c + 1) & 1);      // U buffer last read by the MFMAs of chunk c-1
         if (c + 2 < nchunk) {
-          if (PERSIST && c == 0 && !hk.first) wait_done(hk, 0x8, 0x8);   // chunks 2 and 3: co tile 1's workgroups
+          if (PERSIST && c == 0 && !hk.first && hk.split_wait) wait_done(hk, 0x8, 0x8);   // chunks 2 and 3: co tile 1's workgroups
           if (!dbg_nodma) issue_raw(c + 2, c & 1);        // raw buffer consumed by this wave's transform of chunk c
           wait_vmcnt<12>();                               // raw_{c+1} landed
         } else {
@@ -291,7 +295,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       e_y = w.mask_src != nullptr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const size_t off = (((size_t)b * 16 + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+        const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
         if (e_y) e_yv[q] = *(const f32x4*)(w.mask_src + off);
       }
     } else if (e_combine == 1) {
@@ -308,7 +312,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       e_y = m.y != nullptr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const size_t off = (((size_t)b * 16 + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+        const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
         if (e_y) e_yv[q] = *(const f32x4*)(m.y + off);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -374,7 +378,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
   float esum = 0.0f;
   // emit_quad's plain / stage-combine arithmetic on the operands fetched at the start of the layer (same expressions, same order)
   auto emit_pre = [&](int q, int P, f32x4 v) {
-    const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+    const size_t off = (((size_t)b * QOUT + Q) * kPix + P) * 4;
     if (!e_combine) {
       if (e_relu) {
         v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
@@ -411,7 +415,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       const f32x4 o2 = e_yv[q] + sb * e_h;
       if (e_out2) *(f32x4*)(e_out2 + off) = o2;
       if (e_nchw) {
-        float* o = e_nchw + ((size_t)b * 64 + Q * 4) * kPix + P;
+        float* o = e_nchw + ((size_t)b * (QOUT * 4) + Q * 4) * kPix + P;
         o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
       }
     }
@@ -444,7 +448,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     wait_vmcnt<0>();
     if (wave == 0) pstamp(hk, 7, lane);
     if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_store(hk.done + hk.word0 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0 && hk.announce) __hip_atomic_store(hk.done + hk.word0 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     finish_err(a, esum, wave);
     st.flush(a);
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -548,7 +552,7 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
-                                pa.epoch + 1u, l == 0, n_interleaved == 1};
+                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true};
         wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
       }
       src = src_next;
@@ -558,6 +562,69 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
 }
 
 __global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs pa) { persist_walk(pa, pa.table); }
+
+// ---- the same walk for stacks with 128-channel ends (VidODE's dynamics 128 -> 64 -> 64 -> 128; helpers/utils.py:158-183 with
+// n_inputs = n_outputs = 128, n_units = 64): still four workgroups per sample.  A 128 -> 64 layer is eight input chunks; a
+// 64 -> 128 layer has four co tiles, so every workgroup makes TWO passes (co tiles ct and ct + 2) and announces the layer after the
+// second; the partners' flags are waited for all at once (the chunk <-> co-tile correspondence of the 64 -> 64 case does not hold).
+// A separate kernel: the headline's instantiation above is not touched by these code paths.
+__device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const ConvArgs* table) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nwg = gridDim.x;
+  const int lid = ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);
+  const int rh = lid & 1, ct = (lid >> 1) & 1, group = lid >> 2;
+  const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;
+  const unsigned xtag = pa.epoch << 4;
+  if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, xtag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool fence = false;
+  for (int p = 0; p < 4; ++p) {
+    unsigned v = 0;
+    int n = 0;
+    while (((v = __hip_atomic_load(pa.xcc_of + (lid & ~3) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~15u) != xtag || (v & 15u) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++n > (1 << 23)) {
+        __hip_atomic_store(pa.xcc_of + nwg, pa.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *pa.host_err = 2;
+        break;
+      }
+    }
+    fence |= ((v & 15u) != my_xcc);
+  }
+  fence = __builtin_amdgcn_readfirstlane(fence);
+  const int n_groups = nwg >> 2;
+  for (int b = group; b < pa.batch; b += 2 * n_groups) {
+    const int n_interleaved = b + n_groups < pa.batch ? 2 : 1;
+    for (int l = 0; l < pa.n_layers; ++l) {
+      typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
+      const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
+      if (l + 1 < pa.n_layers && threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
+        const unsigned v = __builtin_nontemporal_load((const unsigned*)&table[l + 1] + threadIdx.x * 16);
+        asm volatile("" ::"v"(v));
+      }
+      const float* src = uniform_ptr(a.src1);
+      const float* u = uniform_ptr(a.w_wino);
+      const int qin = a.qin, qout = a.qout;
+#pragma unroll 1
+      for (int s = 0; s < n_interleaved; ++s) {
+        const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
+        PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
+                          pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false};
+        if (qout == 16) {
+          if (qin == 16) wino_layer<4, false, true, 16>(src, u, 16, a, bs, ct, rh, smem, hk);
+          else           wino_layer<8, false, true, 16>(src, u, 32, a, bs, ct, rh, smem, hk);
+        } else {  // 64 -> 128: co tiles ct and ct + 2; the second pass needs no wait (same input) and announces the layer
+          hk.announce = false;
+          wino_layer<4, false, true, 32>(src, u, 16, a, bs, ct, rh, smem, hk);
+          hk.announce = true;
+          hk.first = true;
+          wino_layer<4, false, true, 32>(src, u, 16, a, bs, ct + 2, rh, smem, hk);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void wino_persist_v_kernel(const PersistArgs pa) { persist_walk_v(pa, pa.table); }
 
 // A short layer sequence (one evaluation of f, one input-gradient chain) with its table IN THE KERNEL ARGUMENTS: nothing to
 // upload or cache, so it also serves callers whose buffers change with every evaluation (adaptive solvers' backward passes, the
@@ -599,9 +666,10 @@ static int launch_wino_n(const ConvArgs& a, hipStream_t stream) {
 }
 
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                        float* out_nchw, int grid, hipStream_t stream) {
+                        float* out_nchw, int grid, hipStream_t stream, bool wide) {
   static bool attr_set = false;
   if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // every workgroup must be resident at once: one per CU (160 KiB of LDS each), `grid` <= number of CUs (checked by the caller)
     int per_cu = 0;
@@ -616,7 +684,8 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   pa.epoch = 0;  // the caller zeroed the flag area
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
-  hipLaunchKernelGGL(wino_persist_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  if (wide) hipLaunchKernelGGL(wino_persist_v_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  else      hipLaunchKernelGGL(wino_persist_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

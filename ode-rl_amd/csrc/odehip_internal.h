@@ -107,7 +107,7 @@ extern thread_local ConvRecorder* g_conv_recorder;
 int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned epoch,
                               unsigned* host_err_dev, int grid, hipStream_t stream);
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                        float* out_nchw, int grid, hipStream_t stream);
+                        float* out_nchw, int grid, hipStream_t stream, bool wide = false);  // wide: the table has 128-channel layers
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_wino5(const ConvArgs& a, hipStream_t stream);  // 5x5 layers with a.w_wino (conv_wino5.hip); 1 = no such form, run the direct kernel
 int launch_bf16(const ConvArgs& a, hipStream_t stream);

@@ -47,8 +47,13 @@ static bool persist_available() {
   return true;
 }
 
-static bool persist_layer_ok(const ConvArgs& a) {
-  return a.qin == 16 && a.q1 == 16 && a.qout == 16 && a.w_wino && !a.w_bf16 && !a.src2 && a.combine >= 0 && a.combine <= 3;
+// 0: not for a persistent walk; 1: a 64 -> 64 layer (the headline kernel); 2: a layer with a 128-channel side (128 -> 64 or
+// 64 -> 128: the wide walk, which has no adaptive error norm)
+static int persist_layer_kind(const ConvArgs& a) {
+  if (!a.w_wino || a.w_bf16 || a.src2 || a.q1 != a.qin || a.combine < 0 || a.combine > 3) return 0;
+  if (a.qin == 16 && a.qout == 16) return 1;
+  if (((a.qin == 32 && a.qout == 16) || (a.qin == 16 && a.qout == 32)) && !(a.combine == 1 && a.cmb.err_partials)) return 2;
+  return 0;
 }
 
 // device copy of `items` (identical content -> the cached copy); null on failure
@@ -154,7 +159,9 @@ int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, i
     }
     if (f->ks != 3 || f->w_fused || (f2 && f2->w_fused) || g_debug_flags) return ODEHIP_OK;
     for (int l = 0; l <= f->n_convs; ++l)
-      if (f->channels[l] != 64) return ODEHIP_OK;
+      if (f->channels[l] != 64 && (small || f->channels[l] != 128)) return ODEHIP_OK;  // (128-channel sides: the wide walk, finish())
+    for (int l = 0; l < f->n_convs; ++l)
+      if (f->channels[l] == 128 && f->channels[l + 1] == 128) return ODEHIP_OK;
     for (int l = 0; l < f->n_convs; ++l)
       if (!f->w_wino[l] || f->w_bf16[l] || (f2 && (!f2->w_wino[l] || f2->w_bf16[l]))) return ODEHIP_OK;
     lock_.lock();
@@ -184,8 +191,15 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;
     if (!active_) return ODEHIP_OK;
     active_ = false;
-    bool all_ok = rec_.count > 0;
-    for (int i = 0; i < rec_.count && all_ok; ++i) all_ok = persist_layer_ok(rec_.items[i]);
+    bool all_ok = rec_.count > 0, wide = false;
+    for (int i = 0; i < rec_.count && all_ok; ++i) {
+      const int kind = persist_layer_kind(rec_.items[i]);
+      all_ok = kind != 0;
+      wide = wide || kind == 2;
+    }
+    if (wide && small_) all_ok = false;
+    // a dopri5 table reads its step size through a device pointer (h_by_value == 0 there): the wide walk only knows the fixed-grid form
+    if (wide && !hbuf) all_ok = false;
     if (small_ && all_ok && rec_.count <= 5) {
       PersistState& P = g_persist;
       bool ready = true;
@@ -241,7 +255,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
-                               kPersistGrid, stream);
+                               kPersistGrid, stream, wide);
       if (rc == ODEHIP_OK) {
         ++g_persist.launches;
         launched_ = true;

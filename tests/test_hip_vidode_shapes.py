@@ -107,3 +107,65 @@ def test_backward_on_vidode_latents(cuda, adjoint):
         assert c.weight.grad.shape == gw.shape
         assert rel_l2(c.weight.grad, gw) <= 1e-4
         assert rel_l2(c.bias.grad, gb) <= 1e-4
+
+
+@pytest.mark.parametrize("method,batch,n_times", [("rk4", 4, 4), ("euler", 64, 3), ("midpoint", 70, 3), ("rk4", 130, 3)])
+def test_persistent_walk_on_vidode_stack_matches_per_layer_launches(cuda, method, batch, n_times):
+    """128 -> 64 -> 64 -> 128 stacks take the wide persistent walk (an eight-chunk first layer, two passes per workgroup over the
+    128-channel last layer): trajectory bit for bit equal to one launch per layer, also with two samples per group (B = 130)."""
+    import os
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    f, _ = _f_v()
+    f = f.to(cuda)
+    z0 = torch.randn(batch, 128, 16, 16, device=cuda, generator=torch.Generator(device=cuda).manual_seed(6)) * 0.5
+    t = torch.arange(n_times, 2 * n_times, dtype=torch.float64, device=cuda) / (2 * n_times)
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        with torch.no_grad():
+            ref = ode_rl_amd.odeint(f, z0, t, method=method)
+            lib.odehip_set_persistent_trajectory(1)
+            n0 = lib.odehip_persistent_trajectory_launches()
+            for _ in range(2):
+                out = ode_rl_amd.odeint(f, z0, t, method=method)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref)
+            if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+                assert lib.odehip_persistent_trajectory_launches() == n0 + 2, "the persistent path did not run"
+        assert lib.odehip_persistent_error(0) == 0
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
+
+
+def test_persistent_walk_on_vidode_stack_gives_identical_gradients(cuda):
+    """saving forward + reverse sweep of the wide walk against one launch per layer: trajectory and every gradient bit for bit"""
+    import os
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    f, _ = _f_v()
+    f = f.to(cuda)
+    z0 = (torch.randn(6, 128, 16, 16, device=cuda, generator=torch.Generator(device=cuda).manual_seed(7)) * 0.5).requires_grad_(True)
+    t = torch.arange(4, 8, dtype=torch.float64, device=cuda) / 8
+    go = torch.randn(4, 6, 128, 16, 16, device=cuda, generator=torch.Generator(device=cuda).manual_seed(8))
+
+    def run():
+        for p in f.parameters():
+            p.grad = None
+        z0.grad = None
+        out = ode_rl_amd.odeint(f, z0, t, method="rk4")
+        (out * go).sum().backward()
+        return [out.detach().clone(), z0.grad.clone()] + [p.grad.clone() for p in f.parameters()]
+
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        ref = run()
+        lib.odehip_set_persistent_trajectory(1)
+        n0 = lib.odehip_persistent_trajectory_launches()
+        got = run()
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() == n0 + 2
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+        assert lib.odehip_persistent_error(0) == 0
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
