@@ -19,6 +19,7 @@
 // One s_barrier per chunk hands U_c / V_c to the consumers and the freed buffers back to the producers.
 // LDS: U[2] 64 KiB + raw[2] 32 KiB + V[2] 64 KiB = 160 KiB.
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "conv_common.h"
@@ -59,6 +60,7 @@ struct PersistHook {
   bool solo;           // the group walks ONE sample: the producers have nothing to prepare while the consumers finish a layer
   bool announce;       // false: the first of a workgroup's two passes over a 128-channel layer -- its flags are stored after the second
   bool split_wait;     // the input chunks 0/1 and 2/3 come from the two co tiles of a 64 -> 64 layer: wait for them separately
+  int sleep6;          // solo: s_sleep(6) periods (0.18 us each) in front of the first poll
 };
 __device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
   if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
@@ -210,13 +212,13 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       if (!hk.first) {
         // One sample per group: the partners cannot be done before this workgroup's own consumers are through their last chunk (~1 us
         // from here): sleep through most of it instead of polling -- a polling wave takes issue slots from the consumer wave of its
-        // SIMD.  Same-box A/B, 6-8 alternations each: 0.37 us of sleep +0.5 %, 0.55 us -2 %, 0.75 us (this) -2.5 .. -4 %, 0.9 us the
-        // same, 1.1 us -2 %, 1.5 us +1 % (the flags are then seen late); a barrier that releases the producers exactly when the
-        // consumers' last MFMA has issued is worse than the fixed sleep (it also holds back the next layer's first weight chunk).
-        if (hk.solo) {
-          __builtin_amdgcn_s_sleep(12);
-          __builtin_amdgcn_s_sleep(12);
-        }
+        // SIMD.  Sweep on one box (ODEHIP_PERSIST_SLEEP = periods of 0.18 us; median of 3 alternations, ms): headline 0: 1.432,
+        // 2: 1.504, 3: 1.435, 4: 1.401, 5: 1.389, 6: 1.409, 8: 1.452; forward + backward 0: 4.75, 4: 4.57, 5: 4.55, 6: 4.54, 8: 4.60;
+        // dopri5 forward 0: 0.799, 4: 0.783, 5: 0.777, 8: 0.796; 128-channel-ended stack 0: 1.640, 4: 1.627, 5: 1.638.  A barrier that
+        // releases the producers exactly when the consumers' last MFMA has issued is worse than the fixed sleep (it also holds back
+        // the next layer's first weight chunk).
+        if (hk.solo)
+          for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
         if (hk.split_wait) wait_done(hk, 0x8, 0x0); else wait_done(hk);
       }
       if (pw == 0) pstamp(hk, 1, lane);
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true, 0};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -490,6 +492,7 @@ struct PersistArgs {
   unsigned* host_err;
   float* out_nchw;        // base of the (T,B,C,16,16) result: table entries carry offsets into it (in `dbg`)
   unsigned long long* stamps;  // diagnostic: [64 layers][8] timestamps of logical workgroup 0, or null
+  int sleep6;             // PersistHook::sleep6
   unsigned epoch;         // 0: the flag area was zeroed for this launch; else the flags persist across launches and every word is
                           // tagged with the epoch of the launch that wrote it (flag = epoch << 10 | layers done; xcc = epoch << 4 | id)
 };
@@ -552,7 +555,7 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
-                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true};
+                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6};
         wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
       }
       src = src_next;
@@ -608,7 +611,7 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
       for (int s = 0; s < n_interleaved; ++s) {
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
-                          pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false};
+                          pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false, pa.sleep6};
         if (qout == 16) {
           if (qin == 16) wino_layer<4, false, true, 16>(src, u, 16, a, bs, ct, rh, smem, hk);
           else           wino_layer<8, false, true, 16>(src, u, 32, a, bs, ct, rh, smem, hk);
@@ -681,6 +684,8 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
   pa.out_nchw = out_nchw;
   pa.stamps = g_debug_buf;
+  static const int sleep6 = [] { const char* e = getenv("ODEHIP_PERSIST_SLEEP"); return e ? atoi(e) : 5; }();  // 5 x 0.18 us (sweep in wino_layer's comment)
+  pa.sleep6 = sleep6;
   pa.epoch = 0;  // the caller zeroed the flag area
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
@@ -704,7 +709,7 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
   SmallPersistArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.pa.table = nullptr; sa.pa.n_layers = n_layers; sa.pa.batch = batch; sa.pa.done = done; sa.pa.xcc_of = xcc_of;
-  sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.epoch = epoch;
+  sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.sleep6 = 5; sa.pa.epoch = epoch;
   for (int i = 0; i < n_layers; ++i) sa.layers[i] = items[i];
   hipLaunchKernelGGL(wino_persist_small_kernel, dim3(grid), dim3(512), kWinoLds, stream, sa);
   ODEHIP_CHECK_HIP(hipGetLastError());
