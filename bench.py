@@ -379,14 +379,14 @@ def main():
             # the whole trajectory is ONE launch of wino_persist_kernel: its algorithmic work = every layer of every f evaluation
             # (339.7 MFLOP per latent frame for A, T=10); duration = the timed region / steps (the copy of
             # z0, the layout kernel and two tiny fills ride along: < 2 %)
-            kernel, launches, flop_per_launch = "wino_persist_kernel", a.steps, F_f * nfe_per_step
+            kernel, launches, flop_per_launch = ("wino_persist_kernel" if a.shape == "A" else "wino_persist_v_kernel"), a.steps, F_f * nfe_per_step
         elif fused_bf16 and persistent == a.steps and a.method != "dopri5":
             # bf16, 64-channel stack: the whole trajectory is ONE launch of ftraj_bf16_kernel (one workgroup per sample)
             kernel, launches, flop_per_launch = "ftraj_bf16_kernel", a.steps, F_f * nfe_per_step
         elif a.method == "dopri5" and persistent > 0 and a.dtype == "f32":
             # dopri5 forward: every attempted step (6 evaluations of f) is one launch of wino_persist_kernel; the two evaluations
             # of the initial-step search run as per-layer launches and are left out of this entry
-            kernel, launches, flop_per_launch = "wino_persist_kernel (one launch per attempted step)", persistent, 6 * F_f
+            kernel, launches, flop_per_launch = ("wino_persist_kernel" if a.shape == "A" else "wino_persist_v_kernel") + " (one launch per attempted step)", persistent, 6 * F_f
             note = "dev time of the whole region / persistent launches; the 2 evaluations of the initial-step search ride along"
         elif fused_bf16:
             kernel, launches, flop_per_launch = "fstack_bf16_kernel", nfe_per_step * a.steps, F_f      # one launch per evaluation of f
@@ -415,7 +415,7 @@ def main():
                        "n_accept": int(fwd_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A" and kernel == "wino_persist_kernel") else None,
+                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A" and kernel == "wino_persist_kernel") else None,  # (PMC passes exist for the headline only)
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
                          "launches_timed": launches, "note": note,
                          # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the fp32 Winograd kernels execute 2.25x fewer

@@ -441,7 +441,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       // have used for workgroup (b, ct, rh), so the controller adds the same numbers in the same order
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-      const int nwg_pl = 4 * hk.batch, lid_pl = b * 4 + ct * 2 + rh;
+      const int nwg_pl = (QOUT / 4) * hk.batch, lid_pl = b * (QOUT / 4) + ct * 2 + rh;  // per-layer grid: (2 co tiles' worth of halves x QOUT / 8, batch)
       const int bid_pl = (nwg_pl & 7) == 0 ? (lid_pl % (nwg_pl >> 3)) * 8 + lid_pl / (nwg_pl >> 3) : lid_pl;
       if (lane == 0) a.cmb.err_partials[bid_pl * 4 + wave] = esum;
     }
@@ -594,6 +594,11 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
     fence |= ((v & 15u) != my_xcc);
   }
   fence = __builtin_amdgcn_readfirstlane(fence);
+  {  // an adaptive solver that finished while this launch was queued: nothing to do (uniform; constant during the launch)
+    typedef const __attribute__((address_space(4))) int ConstI;
+    const int* skip = table[0].skip;
+    if (skip && *(ConstI*)skip) return;
+  }
   const int n_groups = nwg >> 2;
   for (int b = group; b < pa.batch; b += 2 * n_groups) {
     const int n_interleaved = b + n_groups < pa.batch ? 2 : 1;

@@ -48,11 +48,11 @@ static bool persist_available() {
 }
 
 // 0: not for a persistent walk; 1: a 64 -> 64 layer (the headline kernel); 2: a layer with a 128-channel side (128 -> 64 or
-// 64 -> 128: the wide walk, which has no adaptive error norm)
+// 64 -> 128: the wide walk)
 static int persist_layer_kind(const ConvArgs& a) {
   if (!a.w_wino || a.w_bf16 || a.src2 || a.q1 != a.qin || a.combine < 0 || a.combine > 3) return 0;
   if (a.qin == 16 && a.qout == 16) return 1;
-  if (((a.qin == 32 && a.qout == 16) || (a.qin == 16 && a.qout == 32)) && !(a.combine == 1 && a.cmb.err_partials)) return 2;
+  if ((a.qin == 32 && a.qout == 16) || (a.qin == 16 && a.qout == 32)) return 2;
   return 0;
 }
 
@@ -198,8 +198,6 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
       wide = wide || kind == 2;
     }
     if (wide && small_) all_ok = false;
-    // a dopri5 table reads its step size through a device pointer (h_by_value == 0 there): the wide walk only knows the fixed-grid form
-    if (wide && !hbuf) all_ok = false;
     if (small_ && all_ok && rec_.count <= 5) {
       PersistState& P = g_persist;
       bool ready = true;

@@ -169,3 +169,32 @@ def test_persistent_walk_on_vidode_stack_gives_identical_gradients(cuda):
         assert lib.odehip_persistent_error(0) == 0
     finally:
         lib.odehip_set_persistent_trajectory(was)
+
+
+@pytest.mark.parametrize("batch", [3, 64])
+def test_persistent_dopri5_attempts_on_vidode_stack_match_per_layer_launches(cuda, batch):
+    """dopri5 on the 128-channel-ended stack: every attempt (six evaluations, 24 layers) as one launch of the wide walk; the error-norm
+    partials go to the slots the per-layer launches use, so the step sequence and the trajectory are identical bit for bit."""
+    import os
+    import ode_rl_amd
+    lib = ode_rl_amd._lib.load()
+    f, _ = _f_v()
+    f = f.to(cuda)
+    z0 = torch.randn(batch, 128, 16, 16, device=cuda, generator=torch.Generator(device=cuda).manual_seed(9)) * 0.5
+    t = torch.arange(10, 16, dtype=torch.float64, device=cuda) / 20
+    was = lib.odehip_set_persistent_trajectory(0)
+    try:
+        with torch.no_grad():
+            ref = ode_rl_amd.odeint(f, z0, t, method="dopri5", rtol=1e-5, atol=1e-6)
+            st_ref = dict(ode_rl_amd.last_stats)
+            lib.odehip_set_persistent_trajectory(1)
+            n0 = lib.odehip_persistent_trajectory_launches()
+            out = ode_rl_amd.odeint(f, z0, t, method="dopri5", rtol=1e-5, atol=1e-6)
+            st = dict(ode_rl_amd.last_stats)
+        assert torch.equal(out, ref)
+        assert (st["nfe"], st["n_accept"], st["n_reject"]) == (st_ref["nfe"], st_ref["n_accept"], st_ref["n_reject"])
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() > n0, "the persistent path did not run"
+        assert lib.odehip_persistent_error(0) == 0
+    finally:
+        lib.odehip_set_persistent_trajectory(was)
