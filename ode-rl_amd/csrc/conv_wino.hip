@@ -493,6 +493,7 @@ struct PersistArgs {
   float* out_nchw;        // base of the (T,B,C,16,16) result: table entries carry offsets into it (in `dbg`)
   unsigned long long* stamps;  // diagnostic: [64 layers][8] timestamps of logical workgroup 0, or null
   int sleep6;             // PersistHook::sleep6
+  int sleep6_combine;     // added in front of a layer whose input comes out of a stage-combine epilogue
   unsigned epoch;         // 0: the flag area was zeroed for this launch; else the flags persist across launches and every word is
                           // tagged with the epoch of the launch that wrote it (flag = epoch << 10 | layers done; xcc = epoch << 4 | id)
 };
@@ -535,6 +536,7 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
     // ahead and the next row is pulled into L2 a layer ahead
     const float* src = table[0].src1;
     const float* u = table[0].w_wino;
+    int prev_combine = 0;  // the layer whose output this one waits for ended in a Runge-Kutta stage combine (a longer epilogue)
     for (int l = 0; l < pa.n_layers; ++l) {
       // the table is constant for the whole launch: address space 4 lets the compiler fetch its fields with SCALAR loads (as a
       // plain global pointer they become vector loads, each followed by vmcnt(0), because the kernel also stores to global memory)
@@ -555,9 +557,10 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
-                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6};
+                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0)};
         wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
       }
+      prev_combine = a.combine;
       src = src_next;
       u = u_next;
     }
@@ -602,6 +605,7 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
   const int n_groups = nwg >> 2;
   for (int b = group; b < pa.batch; b += 2 * n_groups) {
     const int n_interleaved = b + n_groups < pa.batch ? 2 : 1;
+    int prev_combine = 0;
     for (int l = 0; l < pa.n_layers; ++l) {
       typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
       const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
@@ -616,7 +620,8 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
       for (int s = 0; s < n_interleaved; ++s) {
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
-                          pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false, pa.sleep6};
+                          pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false,
+                          pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0)};
         if (qout == 16) {
           if (qin == 16) wino_layer<4, false, true, 16>(src, u, 16, a, bs, ct, rh, smem, hk);
           else           wino_layer<8, false, true, 16>(src, u, 32, a, bs, ct, rh, smem, hk);
@@ -628,6 +633,7 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
           wino_layer<4, false, true, 32>(src, u, 16, a, bs, ct + 2, rh, smem, hk);
         }
       }
+      prev_combine = a.combine;
     }
   }
 }
@@ -691,6 +697,8 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   pa.stamps = g_debug_buf;
   static const int sleep6 = [] { const char* e = getenv("ODEHIP_PERSIST_SLEEP"); return e ? atoi(e) : 5; }();  // 5 x 0.18 us (sweep in wino_layer's comment)
   pa.sleep6 = sleep6;
+  static const int sleep6c = [] { const char* e = getenv("ODEHIP_PERSIST_SLEEP_COMBINE"); return e ? atoi(e) : 4; }();  // sweep: 0: 1.382, 4: 1.367, 6: 1.370, 8: 1.383, 12: 1.404 ms
+  pa.sleep6_combine = sleep6c;
   pa.epoch = 0;  // the caller zeroed the flag area
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
@@ -714,7 +722,7 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
   SmallPersistArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.pa.table = nullptr; sa.pa.n_layers = n_layers; sa.pa.batch = batch; sa.pa.done = done; sa.pa.xcc_of = xcc_of;
-  sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.sleep6 = 5; sa.pa.epoch = epoch;
+  sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.sleep6 = 5; sa.pa.sleep6_combine = 4; sa.pa.epoch = epoch;
   for (int i = 0; i < n_layers; ++i) sa.layers[i] = items[i];
   hipLaunchKernelGGL(wino_persist_small_kernel, dim3(grid), dim3(512), kWinoLds, stream, sa);
   ODEHIP_CHECK_HIP(hipGetLastError());
