@@ -405,20 +405,26 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     const f32x4 kc = v * e_ks;
     if (e_kout) *(f32x4*)(e_kout + off) = kc;
     if (e_y) {
-      f32x4 sa = kc * e_c1c;
-      f32x4 sb = kc * e_c2c;
+      // a stage writes EITHER the next stage input (out1) OR the step result (out2, + its NCHW frame): only the sum that is stored is
+      // formed (the same expression as before for each)
+      if (e_out1) {
+        f32x4 sa = kc * e_c1c;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j < e_np) {
-          sa += e_kv[j][q] * e_c1[j];
-          sb += e_kv[j][q] * e_c2[j];
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) sa += e_kv[j][q] * e_c1[j];
+        *(f32x4*)(e_out1 + off) = e_yv[q] + sa * e_h;
+      }
+      if (e_out2 || e_nchw) {
+        f32x4 sb = kc * e_c2c;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) sb += e_kv[j][q] * e_c2[j];
+        const f32x4 o2 = e_yv[q] + sb * e_h;
+        if (e_out2) *(f32x4*)(e_out2 + off) = o2;
+        if (e_nchw) {
+          float* o = e_nchw + ((size_t)b * (QOUT * 4) + Q * 4) * kPix + P;
+          o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
         }
-      if (e_out1) *(f32x4*)(e_out1 + off) = e_yv[q] + sa * e_h;
-      const f32x4 o2 = e_yv[q] + sb * e_h;
-      if (e_out2) *(f32x4*)(e_out2 + off) = o2;
-      if (e_nchw) {
-        float* o = e_nchw + ((size_t)b * (QOUT * 4) + Q * 4) * kPix + P;
-        o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
       }
     }
   };
