@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 5 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 6 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -283,13 +283,17 @@ typedef struct odehip_encoder_grads {  /* outputs, each shaped like its paramete
 /* Forward that keeps the conv outputs of every frame in `workspace` (which the caller must leave untouched until the
  * backward call), then the reverse sweep: grad_mean / grad_std (B,out_ch,16,16) -> grad_inputs (T,B,C,16,16) and the
  * gradient of every parameter of the encoder dynamics, the ConvGRU cell (incl. GroupNorm affine) and the 1x1 head.
+ * run_backwards as in odehip_odeconvgru_encode (the same value in both calls); latent_nchw (B,T,C,16,16) or NULL receives
+ * run_ode_conv_gru's latent_ys, grad_latent_nchw (same shape) or NULL is the gradient that arrives through it.
  * Channel counts must be multiples of 64, encoder dynamics 3x3.  Deterministic (no float atomics). */
 size_t odehip_encoder_train_workspace_bytes(const odehip_encoder* e, int n_frames, int batch);
 int odehip_odeconvgru_encode_train(const odehip_encoder* e, const float* inputs_nchw, const double* t_host, int n_frames, int batch,
-                                   float* mean_nchw, float* std_nchw, void* workspace, size_t workspace_bytes, void* stream);
+                                   int run_backwards, float* mean_nchw, float* std_nchw, float* latent_nchw, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const odehip_encoder_bwd* eb, const double* t_host, int n_frames,
-                                      int batch, const float* grad_mean_nchw, const float* grad_std_nchw, float* grad_inputs_nchw,
-                                      const odehip_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+                                      int batch, int run_backwards, const float* grad_mean_nchw, const float* grad_std_nchw,
+                                      const float* grad_latent_nchw, float* grad_inputs_nchw, const odehip_encoder_grads* grads,
+                                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- odeint, adaptive dopri5 (torchdiffeq Dopri5Solver; the reference's default method, configs.yaml:79) ------ */
 

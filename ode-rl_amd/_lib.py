@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
-ABI_VERSION = 5   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
+ABI_VERSION = 6   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
 MAX_LAYERS = 8
 MAX_STAGES = 7
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
@@ -191,12 +191,12 @@ SIGNATURES = {
                                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_encoder_train_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(EncoderDesc), ctypes.c_int, ctypes.c_int]),
     "odehip_odeconvgru_encode_train": (ctypes.c_int, [ctypes.POINTER(EncoderDesc), ctypes.c_void_p,
-                                                      ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
-                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                                      ctypes.c_void_p]),
+                                                      ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_odeconvgru_encode_backward": (ctypes.c_int, [ctypes.POINTER(EncoderDesc), ctypes.POINTER(EncoderBwd),
-                                                         ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
-                                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                         ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                          ctypes.POINTER(EncoderGrads), ctypes.c_void_p, ctypes.c_size_t,
                                                          ctypes.c_void_p]),
     "odehip_odeint_dopri5": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),

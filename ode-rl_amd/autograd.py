@@ -100,31 +100,32 @@ def cell_with_grad(packed, x, h):
 
 
 class _EncodeFn(torch.autograd.Function):
-    """ODEConvGRUCell.forward under autograd: csrc/convgru_backward.hip keeps the per-frame conv outputs and sweeps back."""
+    """ODEConvGRUCell.forward / run_ode_conv_gru under autograd: csrc/convgru_backward.hip keeps the per-frame conv outputs and
+    sweeps back; the gradient may arrive through (mean, std) and, when latent_ys was asked for, through latent_ys."""
 
     @staticmethod
-    def forward(ctx, inputs, timesteps, enc, *params):
+    def forward(ctx, inputs, timesteps, enc, want_latent, run_backwards, *params):
         ctx.mode = hip_ops.current_compute_dtype()
-        mean, std, saved = hip_ops.odeconvgru_encode_train(enc, inputs.detach(), timesteps)
-        ctx.enc, ctx.saved = enc, saved
+        mean, std, latent, saved = hip_ops.odeconvgru_encode_train(enc, inputs.detach(), timesteps, want_latent, run_backwards)
+        ctx.enc, ctx.saved, ctx.want_latent = enc, saved, want_latent
         ctx.versions = tuple(p._version for p in params)
         ctx.params = params
-        return mean, std
+        return (mean, std, latent) if want_latent else (mean, std)
 
     @staticmethod
     @_pinned
-    def backward(ctx, grad_mean, grad_std):
+    def backward(ctx, grad_mean, grad_std, grad_latent=None):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("an encoder parameter was modified in place between forward and backward")
         if ctx.saved is None:
             raise RuntimeError("the encoder's saved activations were already consumed (backward called twice)")
-        gin, grads = hip_ops.odeconvgru_encode_backward(ctx.enc, ctx.saved, grad_mean, grad_std)
+        gin, grads = hip_ops.odeconvgru_encode_backward(ctx.enc, ctx.saved, grad_mean, grad_std, grad_latent if ctx.want_latent else None)
         ctx.saved = None
-        return (gin, None, None) + tuple(grads)
+        return (gin, None, None, None, None) + tuple(grads)
 
 
-def encode_with_grad(enc, inputs, timesteps):
-    return _EncodeFn.apply(inputs, timesteps, enc, *hip_ops.encoder_params(enc))
+def encode_with_grad(enc, inputs, timesteps, want_latent=False, run_backwards=True):
+    return _EncodeFn.apply(inputs, timesteps, enc, bool(want_latent), bool(run_backwards), *hip_ops.encoder_params(enc))
 
 
 class _WarpCompositeFn(torch.autograd.Function):

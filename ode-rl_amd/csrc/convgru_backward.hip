@@ -324,9 +324,25 @@ static int check_encoder(const odehip_encoder* e, const char* who) {
   return ODEHIP_OK;
 }
 
-static float frame_dt(const double* t_host, int n_frames, int idx) {  // ODEConvGRUCell.py:47,73
-  const int i = n_frames - 1 - idx;
-  return idx == 0 ? (float)(t_host[n_frames - 1] - (t_host[n_frames - 1] + 0.01)) : (float)(t_host[i] - t_host[i + 1]);
+// Euler step in front of the idx-th visited frame (ODEConvGRUCell.py:47,73): first t[-1] - (t[-1] + 0.01); after visiting frame j the
+// loop sets (prev_t, t_i) = (t[j], t[j-1]) -- Python indexing, so j = 0 wraps to t[-1].  Frames are visited T-1 .. 0 (run_backwards,
+// what forward() does) or 0 .. T-1.
+static float frame_dt(const double* t_host, int n_frames, int idx, int run_backwards) {
+  if (idx == 0) return (float)(t_host[n_frames - 1] - (t_host[n_frames - 1] + 0.01));
+  const int j = run_backwards ? n_frames - idx : idx - 1;  // frame visited at iteration idx - 1
+  return (float)(t_host[(j + n_frames - 1) % n_frames] - t_host[j]);
+}
+static int visited_frame(int n_frames, int idx, int run_backwards) { return run_backwards ? n_frames - 1 - idx : idx; }
+
+// gh (Q4) += grad_latent[:, slot] (NCHW slice of a (B,T,C,16,16) tensor): the gradient that arrives through latent_ys
+__global__ __launch_bounds__(256) void add_nchw_slice_to_q4_kernel(const float* __restrict__ src, long long batch_stride,
+                                                                   float* __restrict__ dst, int total, int quads) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = idx & 255, bq = idx >> 8, b = bq / quads, q = bq - b * quads;
+  const float* s = src + (size_t)b * batch_stride + (size_t)q * 4 * kPix + p;
+  f32x4* d = (f32x4*)(dst + (size_t)idx * 4);
+  *d += f32x4{s[0], s[kPix], s[2 * kPix], s[3 * kPix]};
 }
 
 }  // namespace odehip
@@ -339,8 +355,8 @@ extern "C" size_t odehip_encoder_train_workspace_bytes(const odehip_encoder* e, 
 }
 
 extern "C" int odehip_odeconvgru_encode_train(const odehip_encoder* e, const float* inputs_nchw, const double* t_host, int n_frames,
-                                              int batch, float* mean_nchw, float* std_nchw, void* workspace, size_t workspace_bytes,
-                                              void* stream_) {
+                                              int batch, int run_backwards, float* mean_nchw, float* std_nchw, float* latent_nchw,
+                                              void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_encoder(e, "odeconvgru_encode_train");
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(inputs_nchw && t_host && mean_nchw && std_nchw && workspace, "odeconvgru_encode_train: null pointer");
@@ -352,14 +368,14 @@ extern "C" int odehip_odeconvgru_encode_train(const odehip_encoder* e, const flo
   const int C = L.C, NH = L.NH;
   const size_t hs_b = (size_t)batch * C * kPix * 4;
   float dts_h[64];
-  for (int idx = 0; idx < n_frames; ++idx) dts_h[idx] = frame_dt(t_host, n_frames, idx);
+  for (int idx = 0; idx < n_frames; ++idx) dts_h[idx] = frame_dt(t_host, n_frames, idx, run_backwards);
   if ((rc = upload_bytes(L.p(ws, L.off_dts), dts_h, (size_t)n_frames * 4, stream)) != ODEHIP_OK) return rc;
   rc = odehip_nchw_to_q4(inputs_nchw, L.frame(ws, 0), n_frames * batch, C, stream);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_CHECK_HIP(hipMemsetAsync(L.hstate(ws, 0), 0, hs_b, stream));
   float* hidv[ODEHIP_MAX_LAYERS];
   for (int idx = 0; idx < n_frames; ++idx) {
-    const int i = n_frames - 1 - idx;
+    const int i = visited_frame(n_frames, idx, run_backwards);
     CombineArgs c;
     memset(&c, 0, sizeof(c));
     c.k_scale = 1.0f;
@@ -371,7 +387,8 @@ extern "C" int odehip_odeconvgru_encode_train(const odehip_encoder* e, const flo
     rc = enqueue_f_saving(&e->f_enc, L.hstate(ws, idx), batch, hidv, L.p(ws, L.off_ping), L.p(ws, L.off_pong), &c, nullptr, nullptr,
                           stream);
     if (rc != ODEHIP_OK) return rc;
-    rc = cell_step_q4(&e->cell, L.frame(ws, i), L.per(ws, L.off_hode, idx, L.hs), L.hstate(ws, idx + 1), nullptr, 0, batch,
+    float* lat = latent_nchw ? latent_nchw + (size_t)idx * C * kPix : nullptr;  // latent_ys (B,T,C,H,W): slot idx of each sample
+    rc = cell_step_q4(&e->cell, L.frame(ws, i), L.per(ws, L.off_hode, idx, L.hs), L.hstate(ws, idx + 1), lat, (long long)n_frames * C * kPix, batch,
                       L.per(ws, L.off_gates, idx, 2 * L.hs), L.per(ws, L.off_z, idx, L.hs), L.per(ws, L.off_rh, idx, L.hs),
                       L.per(ws, L.off_cand, idx, L.hs), stream);
     if (rc != ODEHIP_OK) return rc;
@@ -388,9 +405,9 @@ extern "C" int odehip_odeconvgru_encode_train(const odehip_encoder* e, const flo
 }
 
 extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const odehip_encoder_bwd* eb, const double* t_host,
-                                                 int n_frames, int batch, const float* grad_mean_nchw, const float* grad_std_nchw,
-                                                 float* grad_inputs_nchw, const odehip_encoder_grads* gr, void* workspace,
-                                                 size_t workspace_bytes, void* stream_) {
+                                                 int n_frames, int batch, int run_backwards, const float* grad_mean_nchw,
+                                                 const float* grad_std_nchw, const float* grad_latent_nchw, float* grad_inputs_nchw,
+                                                 const odehip_encoder_grads* gr, void* workspace, size_t workspace_bytes, void* stream_) {
   int rc = check_encoder(e, "odeconvgru_encode_backward");
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(eb && t_host && grad_mean_nchw && grad_std_nchw && grad_inputs_nchw && gr && workspace,
@@ -447,7 +464,12 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
 
   // ---- frames, last processed first
   for (int idx = T - 1; idx >= 0; --idx) {
-    const int i = T - 1 - idx;
+    const int i = visited_frame(T, idx, run_backwards);
+    if (grad_latent_nchw) {  // gh = gradient w.r.t. the state after the idx-th visited frame: + what arrives through latent_ys[:, idx]
+      const int total = batch * (C / 4) * kPix;
+      hipLaunchKernelGGL(add_nchw_slice_to_q4_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                         grad_latent_nchw + (size_t)idx * C * kPix, (long long)T * C * kPix, gh, total, C / 4);
+    }
     float* g_cand = L.per(ws, L.off_gcand, idx, L.hs);
     float* g_gates = L.per(ws, L.off_ggates, idx, 2 * L.hs);
     const float* h_ode = L.per(ws, L.off_hode, idx, L.hs);
@@ -501,7 +523,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
     for (int idx = 0; idx < T; ++idx) {
       host[idx].g = L.gp(ws, idx, l);
       host[idx].a = l == 0 ? L.hstate(ws, idx) : L.hidden(ws, idx, l - 1);
-      host[idx].scale = frame_dt(t_host, T, idx);
+      host[idx].scale = frame_dt(t_host, T, idx, run_backwards);
       host[idx].pad_[0] = host[idx].pad_[1] = host[idx].pad_[2] = 0.0f;
     }
     if ((rc = put_table(T)) != ODEHIP_OK) return rc;
@@ -518,7 +540,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
     for (int half = 0; half < 2; ++half) {
       for (int idx = 0; idx < T; ++idx) {
         host[idx].g = L.per(ws, J.g_off, idx, gbytes);
-        host[idx].a = half == 0 ? L.frame(ws, T - 1 - idx) : L.per(ws, J.a2_off, idx, L.hs);
+        host[idx].a = half == 0 ? L.frame(ws, visited_frame(T, idx, run_backwards)) : L.per(ws, J.a2_off, idx, L.hs);
         host[idx].scale = 1.0f;
         host[idx].pad_[0] = host[idx].pad_[1] = host[idx].pad_[2] = 0.0f;
       }

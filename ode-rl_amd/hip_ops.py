@@ -746,8 +746,9 @@ def _encoder_bwd_desc(enc):
     return b
 
 
-def odeconvgru_encode_train(enc, inputs, timesteps):
-    """Forward of the training path: returns (mean, std, saved) -- `saved` holds the workspace the backward call needs."""
+def odeconvgru_encode_train(enc, inputs, timesteps, want_latent=False, run_backwards=True):
+    """Forward of the training path: returns (mean, std, latent_ys or None, saved) -- `saved` holds the workspace the backward
+    call needs."""
     require_device_tensor(inputs, "inputs")
     d = enc.refresh()
     inputs = inputs.contiguous()
@@ -761,15 +762,16 @@ def odeconvgru_encode_train(enc, inputs, timesteps):
     ws = alloc_workspace(nbytes, inputs.device)   # owned by this call's graph node
     mean = torch.empty((b, d.out_ch, 16, 16), dtype=torch.float32, device=inputs.device)
     std = torch.empty_like(mean)
+    latent = torch.empty((b, t, c, 16, 16), dtype=torch.float32, device=inputs.device) if want_latent else None
     tarr = (ctypes.c_double * t)(*t64)
-    _lib.check(lib.odehip_odeconvgru_encode_train(ctypes.byref(d), _ptr(inputs), tarr, t, b, _ptr(mean), _ptr(std), _ptr(ws),
-                                                  ws.numel(), _stream()))
-    return mean, std, (ws, t64, t, b, c)
+    _lib.check(lib.odehip_odeconvgru_encode_train(ctypes.byref(d), _ptr(inputs), tarr, t, b, int(bool(run_backwards)), _ptr(mean),
+                                                  _ptr(std), _ptr(latent), _ptr(ws), ws.numel(), _stream()))
+    return mean, std, latent, (ws, t64, t, b, c, int(bool(run_backwards)))
 
 
-def odeconvgru_encode_backward(enc, saved, grad_mean, grad_std):
-    """(grad_inputs (T,B,C,16,16), [gradient of every tensor of encoder_params(enc)])."""
-    ws, t64, t, b, c = saved
+def odeconvgru_encode_backward(enc, saved, grad_mean, grad_std, grad_latent=None):
+    """(grad_inputs (T,B,C,16,16), [gradient of every tensor of encoder_params(enc)]); grad_latent: what arrives through latent_ys."""
+    ws, t64, t, b, c, run_backwards = saved
     d = enc.refresh()
     bw = _encoder_bwd_desc(enc)
     dev = ws.device
@@ -777,6 +779,11 @@ def odeconvgru_encode_backward(enc, saved, grad_mean, grad_std):
     grad_std = (torch.zeros((b, d.out_ch, 16, 16), device=dev) if grad_std is None else grad_std).contiguous()
     require_device_tensor(grad_mean, "grad_mean")
     require_device_tensor(grad_std, "grad_std")
+    if grad_latent is not None:
+        grad_latent = grad_latent.contiguous()
+        require_device_tensor(grad_latent, "grad_latent")
+        if tuple(grad_latent.shape) != (b, t, c, 16, 16):
+            raise ValueError(f"grad_latent must be ({b},{t},{c},16,16), got {tuple(grad_latent.shape)}")
     params = encoder_params(enc)
     grads = [torch.empty_like(p) for p in params]
     g = _lib.EncoderGrads()
@@ -788,9 +795,9 @@ def odeconvgru_encode_backward(enc, saved, grad_mean, grad_std):
      g.b_head1) = (x.data_ptr() for x in grads[2 * nl:])
     gin = torch.empty((t, b, c, 16, 16), dtype=torch.float32, device=dev)
     tarr = (ctypes.c_double * t)(*t64)
-    _lib.check(_lib.load().odehip_odeconvgru_encode_backward(ctypes.byref(d), ctypes.byref(bw), tarr, t, b, _ptr(grad_mean),
-                                                             _ptr(grad_std), _ptr(gin), ctypes.byref(g), _ptr(ws), ws.numel(),
-                                                             _stream()))
+    _lib.check(_lib.load().odehip_odeconvgru_encode_backward(ctypes.byref(d), ctypes.byref(bw), tarr, t, b, run_backwards,
+                                                             _ptr(grad_mean), _ptr(grad_std), _ptr(grad_latent), _ptr(gin),
+                                                             ctypes.byref(g), _ptr(ws), ws.numel(), _stream()))
     return gin, grads
 
 

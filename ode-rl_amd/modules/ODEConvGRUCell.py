@@ -46,10 +46,11 @@ class ODEConvGRUCell(nn.Module):
 
     def run_ode_conv_gru(self, inputs, timesteps, run_backwards=True, mask=None):
         """Returns (last yi, latent_ys (B,T,C,H,W)) as the reference (:39-78): frames visited T-1 .. 0 (run_backwards, what
-        forward() uses, :33) or 0 .. T-1; slot k of latent_ys is the state after the k-th visited frame.  Inference only: the
-        training path differentiates forward()'s (mean, std), which is all the reference's models consume."""
+        forward() uses, :33) or 0 .. T-1; slot k of latent_ys is the state after the k-th visited frame.  Differentiable: under
+        autograd the training kernels (csrc/convgru_backward.hip) take the gradient that arrives through latent_ys."""
         if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("run_ode_conv_gru(HIP): latent_ys does not carry gradients; use forward() (mean, std) "
-                                      "for training or call under torch.no_grad()")
+            from ..autograd import encode_with_grad
+            _, _, latent = encode_with_grad(self._packed(), inputs, timesteps, want_latent=True, run_backwards=run_backwards)
+            return latent[:, -1], latent
         _, _, latent = hip_ops.odeconvgru_encode(self._packed(), inputs, timesteps, want_latent=True, run_backwards=run_backwards)
         return latent[:, -1], latent

@@ -112,3 +112,40 @@ def test_convgru_cell_backward_matches_autograd_through_oracle(cuda):
     assert rel_l2(xd.grad, rg[0]) <= 2e-4 and rel_l2(hd.grad, rg[1]) <= 2e-4
     for (name, p), g in zip(cell.named_parameters(), rg[2:]):
         assert name in names and rel_l2(p.grad, g) <= 2e-4, (name, rel_l2(p.grad, g))
+
+
+@pytest.mark.parametrize("run_backwards,T,B", [(True, 3, 2), (False, 3, 2), (False, 1, 1)])
+def test_run_ode_conv_gru_is_differentiable_through_latent_ys(cuda, run_backwards, T, B):
+    """`run_ode_conv_gru` (ODEConvGRUCell.py:39-78) under autograd, both visiting orders: the gradient arrives through latent_ys (all
+    slots) and through the last state; frames' and every cell / dynamics parameter's gradient against autograd through the oracle
+    (the 1x1 head is not on this path: its parameters get zero gradients there and are skipped)."""
+    from oracle import reference_modules as rm
+    ch = 64
+    enc = _build(ch)
+    g = torch.Generator().manual_seed(17)
+    inputs = torch.randn(T, B, ch, 16, 16, generator=g) * 0.5
+    t = torch.arange(T, dtype=torch.float64) / 8
+    glat = torch.randn(B, T, ch, 16, 16, generator=g)
+    glast = torch.randn(B, ch, 16, 16, generator=g)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    ws, bs = rm.split_convnet_state(sd, "ode_func.gradient_net.")
+    cell = {k[len("cgru_cell."):]: v for k, v in sd.items() if k.startswith("cgru_cell.")}
+    head = {k[len("transform_z0."):]: v for k, v in sd.items() if k.startswith("transform_z0.")}
+    xr = inputs.clone().requires_grad_(True)
+    _, _, lat_ref = rm.ode_convgru_encode(xr, t, rm.ode_func(ws, bs), cell, head, run_backwards=run_backwards)
+    names = [k for k in sd if not k.startswith("transform_z0.")]
+    ref = torch.autograd.grad([lat_ref, lat_ref[:, -1]], [xr] + [sd[k] for k in names], [glat, glast])
+
+    enc = enc.to(cuda)
+    x = inputs.to(cuda).requires_grad_(True)
+    last, lat = enc.run_ode_conv_gru(x, t.to(cuda), run_backwards=run_backwards)
+    assert lat.requires_grad and lat.shape == (B, T, ch, 16, 16)
+    assert rel_l2(lat, lat_ref) <= 5e-5 and torch.equal(last, lat[:, -1])
+    torch.autograd.backward([lat, last], [glat.to(cuda), glast.to(cuda)])
+    assert rel_l2(x.grad, ref[0]) <= 2e-4
+    got = dict(enc.named_parameters())
+    bad = {k: rel_l2(got[k].grad, r) for k, r in zip(names, ref[1:]) if rel_l2(got[k].grad, r) > 2e-4}
+    assert not bad, bad
+    with torch.no_grad():    # the inference kernels give the same latent states
+        _, lat_inf = enc.run_ode_conv_gru(x.detach(), t.to(cuda), run_backwards=run_backwards)
+    assert rel_l2(lat_inf, lat) <= 1e-6
