@@ -3,6 +3,8 @@ against an emulation of exactly that arithmetic in the oracle (operands rounded 
 one conv layer rel-L2 <= 1e-5 (bf16 products are exact in fp32); a stack / trajectory <= 1e-3 and gradients <= 5e-3, because
 an activation within fp32 round-off of a bf16 rounding boundary may round the other way in two correct implementations;
 and against the exact fp32 oracle to show the size of the bf16 error itself (<= 2e-2)."""
+import os
+
 import pytest
 import torch
 
@@ -222,7 +224,8 @@ def test_whole_trajectory_launch_is_bit_identical_to_per_evaluation_launches(cud
             n0 = lib.odehip_persistent_trajectory_launches()
             for _ in range(2):
                 out = ode_rl_amd.odeint(f, z0.to(cuda), t, method=method)
-        assert lib.odehip_persistent_trajectory_launches() == n0 + 2, "the whole-trajectory launch did not run"
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() == n0 + 2, "the whole-trajectory launch did not run"
         assert torch.equal(out, ref)
     finally:
         lib.odehip_set_persistent_trajectory(was)
@@ -264,7 +267,8 @@ def test_whole_trajectory_training_matches_per_evaluation_launches(cuda, bf16_mo
         lib.odehip_set_persistent_trajectory(1)
         n0 = lib.odehip_persistent_trajectory_launches()
         got = run()
-        assert lib.odehip_persistent_trajectory_launches() == n0 + 1, "the whole-trajectory saving forward did not run"
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() == n0 + 1, "the whole-trajectory saving forward did not run"
         again = run()
     finally:
         lib.odehip_set_persistent_trajectory(was)
@@ -308,7 +312,8 @@ def test_whole_trajectory_launches_with_other_stack_depths(cuda, bf16_mode, n_la
         lib.odehip_set_persistent_trajectory(1)
         n0 = lib.odehip_persistent_trajectory_launches()
         got_f, got_t = run(False), run(True)
-        assert lib.odehip_persistent_trajectory_launches() == n0 + 2
+        if os.environ.get("ODEHIP_PERSISTENT", "1") != "0":
+            assert lib.odehip_persistent_trajectory_launches() == n0 + 2
     finally:
         lib.odehip_set_persistent_trajectory(was)
     assert torch.equal(got_f[0], ref_f[0]) and torch.equal(got_t[0], ref_t[0])
