@@ -23,7 +23,7 @@ import os
 import sys
 import time
 
-import torch
+torch = None    # imported by main() AFTER the self-launch decision: the parent of a --gpus N launch never loads torch (or any GPU runtime)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -33,16 +33,42 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak 
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); the bf16 conv is NOT bound by it (launch boundary, staging, epilogue)
 
 
+TRAFFIC_SOURCES = ("conv_wino.hip", "persist.hip", "persist.h", "conv_common.h")   # what the headline kernel is compiled from
+
+
+def source_digest():
+    """sha256 over the sources of the dominant kernel: the key that ties a committed PMC summary to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, "ode-rl_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def profiled_traffic():
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (separate --pmc passes,
-    FETCH_SIZE doubled per the gfx950 correction); None if no summary is present.  Not measured live."""
-    for tag in ("r02", "r01"):
+    """(HBM bytes per launch of the dominant kernel, provenance) from the newest committed rocprofv3 PMC summary (separate --pmc
+    passes, FETCH_SIZE doubled per the gfx950 correction).  NOT measured live -- so it is only reported when the summary was
+    taken on exactly the kernel sources of this tree (tools/summarize_profile.py stores their digest and the commit);
+    otherwise (None, why): a stale number is dropped rather than carried along."""
+    try:
+        now = source_digest()
+    except OSError as e:
+        return None, f"kernel sources unreadable: {e!r}"
+    why = "no PMC summary under profiles/"
+    for tag in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")) as fh:
-                return float(json.load(fh)["notes"]["hbm_bytes_per_launch"])
+                notes = json.load(fh)["notes"]
+            val = float(notes["hbm_bytes_per_launch"])
         except Exception:
             continue
-    return None
+        if notes.get("source_sha256") == now:
+            return val, {"profile": f"profiles/{tag}_rocprof_summary.json", "git_head": notes.get("git_head"), "source_sha256": now[:16],
+                         "how": "rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), not measured by this run"}
+        why = f"profiles/{tag}_rocprof_summary.json was taken on other kernel sources (digest {str(notes.get('source_sha256'))[:16]} != {now[:16]}): dropped as stale"
+        break
+    return None, why
 
 
 def parse():
@@ -136,28 +162,62 @@ def cpu_baseline(state, z0, t, method, budget_s, rtol=1e-4, atol=1e-5):
                       "torchdiffeq is not installed: the oracle's restatement of torchdiffeq 0.2.1 is what is timed"}
 
 
-def self_launch(a):
-    """--gpus N without a launcher: one child process of this file per rank.  Runs BEFORE anything in this process touches
-    the GPU (torch.cuda.device_count() does not initialise it), and never replaces this process: children are spawned, waited
-    for, and their exit code is propagated.  Rank 0's stdout (the JSON line) is inherited."""
+def visible_gpu_count():
+    """GPUs this process may use, counted WITHOUT any HIP / HSA / torch.cuda call (the launcher parent must not open the GPU
+    runtime: on this pool a GPU-initialised process must not spawn-and-exec).  An explicit visibility list wins (the runtime
+    would apply it to the KFD nodes anyway); otherwise the KFD topology in sysfs: a node with simd_count > 0 is a GPU.
+    Returns None when neither source exists (no amdgpu driver: a CPU-only container)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            continue
+    return n
+
+
+def self_launch(a, grace_s=10.0):
+    """--gpus N without a launcher: one child process of this file per rank.  The parent makes NO GPU-runtime call -- torch is
+    not even imported here (`tests/test_bench_launch.py` asserts it) -- and never replaces itself: children are spawned, waited
+    for, and the first non-zero exit code is propagated.  Rank 0's stdout (the JSON line) is inherited.  A rank that fails makes
+    the parent terminate the others (they would wait at the rendezvous for ever) and, if one ignores SIGTERM for `grace_s`
+    seconds (stuck in a GPU wait), kill it: the parent always exits."""
     import socket
     import subprocess
+    assert "torch" not in sys.modules or os.environ.get("ODEHIP_BENCH_ALLOW_TORCH_IN_PARENT"), "the launcher parent must not load torch"
     n = a.gpus
     if not a.launch_check and not os.environ.get("ODEHIP_BENCH_REHEARSAL"):
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpu_count()
+        if have is not None and have < n:
             raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible (set ODEHIP_BENCH_REHEARSAL=1 to rehearse {n} ranks on one GPU over gloo)")
+        # have is None: no sysfs topology to count from -- every rank checks LOCAL_RANK < device_count() itself and exits non-zero
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL's intra-node transport exchanges buffers between the ranks' processes through HIP IPC
+        # handles, and this pool's host driver only supports the dmabuf flavour (legacy mode fails with `hipIpcGetMemHandle: invalid
+        # argument`).  The image exports it already; setdefault keeps a caller's own value and only fills the gap (DESIGN.md section 6)
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     alive = list(procs)
+    deadline = None
     while alive:
         time.sleep(0.05)
         for p in list(alive):
@@ -169,7 +229,30 @@ def self_launch(a):
                 rc = code
                 for q in alive:          # a failed rank would leave the others waiting at the rendezvous: stop exactly those PIDs
                     q.terminate()
+                deadline = time.monotonic() + grace_s
+        if deadline is not None and alive and time.monotonic() > deadline:
+            for q in alive:              # SIGTERM ignored (a rank stuck in a GPU wait): SIGKILL the exact PIDs we started
+                q.kill()
+            deadline = time.monotonic() + grace_s
     raise SystemExit(rc)
+
+
+def collective_identity(dist_mod, rank, local, world, dev, rehearsal):
+    """What the process group really is, gathered from every rank: backend, the group's own world size, and one device identity
+    per rank (index, name, PCI domain:bus:device, uuid) -- so a scaling line proves N distinct GPUs took part."""
+    pr = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local, "device_index": dev.index, "name": pr.name, "arch": getattr(pr, "gcnArchName", None),
+          "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
+          "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
+    if dist_mod is None:
+        return {"backend": None, "world_size": 1, "ranks": [me], "distinct_devices": 1}
+    allr = [None] * world
+    dist_mod.all_gather_object(allr, me)
+    ids = {(r["pci"], r["uuid"]) for r in allr}
+    if not rehearsal and len(ids) != world:
+        raise SystemExit(f"--gpus {world}: the ranks do not sit on {world} distinct GPUs: {allr}")
+    return {"backend": dist_mod.get_backend(), "world_size": dist_mod.get_world_size(), "ranks": allr, "distinct_devices": len(ids),
+            "rehearsal_one_gpu": bool(rehearsal)}
 
 
 def launch_check(rank, world):
@@ -179,8 +262,12 @@ def launch_check(rank, world):
     x = torch.tensor([float(rank)], dtype=torch.float64)
     dist.barrier()
     dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    ids = [None] * world
+    dist.all_gather_object(ids, {"rank": rank, "pid": os.getpid()})
     if rank == 0:
-        print(json.dumps({"launch_check": True, "world": world, "max_rank_seen": int(x.item())}), flush=True)
+        print(json.dumps({"launch_check": True, "world": world, "max_rank_seen": int(x.item()),
+                          "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                         "ranks": [i["rank"] for i in ids], "distinct_pids": len({i["pid"] for i in ids})}}), flush=True)
     dist.destroy_process_group()
 
 
@@ -188,6 +275,8 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)     # does not return
+    global torch
+    import torch           # only a rank (or the single-GPU run) loads torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,8 +295,12 @@ def main():
             os.environ["ODEHIP_PERSISTENT"] = "0"
             dist.init_process_group("gloo")
         else:
+            have = torch.cuda.device_count()
+            if local >= have:
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {have} GPU(s) visible")
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rehearsal = bool(os.environ.get("ODEHIP_BENCH_REHEARSAL")) and world > 1
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -312,6 +405,7 @@ def main():
         return o, float(wt.item()), ev0.elapsed_time(ev1), per[len(per) // 2], n_persist
 
     lib = ode_rl_amd._lib.load()
+    collective = collective_identity(dist, rank, local, world, dev, rehearsal)
     out, wall, dev_ms, median_ms, persistent = measure(step, a.steps, a.warmup)
     assert out.shape == (T, a.batch, C0, 16, 16) and bool(torch.isfinite(out).all())
     fwd_stats = dict(ode_rl_amd.last_stats) if a.method == "dopri5" else {}
@@ -396,6 +490,8 @@ def main():
         per_launch_s = dev_ms * 1e-3 / launches                      # HIP events over the timed region, incl. inter-kernel gaps
         achieved = flop_per_launch / per_launch_s / 1e12
         peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        traffic, traffic_src = (profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A" and kernel == "wino_persist_kernel")
+                                else (None, "PMC passes exist for the headline workload only"))
         res = {
             "metric": "integrated latent frames/sec (ODEConvGRU, MovingMNIST)",
             "value": world * a.batch * T * a.steps / wall,
@@ -415,13 +511,13 @@ def main():
                        "n_accept": int(fwd_stats.get("n_accept", 0)) if a.method == "dopri5" else None},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": profiled_traffic() if (a.batch == 64 and a.dtype == "f32" and a.shape == "A" and kernel == "wino_persist_kernel") else None,  # (PMC passes exist for the headline only)
+                         "traffic": traffic, "traffic_provenance": traffic_src,   # (PMC passes exist for the headline only)
                          "flop_per_launch": flop_per_launch, "avg_launch_us": per_launch_s * 1e6,
                          "launches_timed": launches, "note": note,
                          # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the fp32 Winograd kernels execute 2.25x fewer
                          # on the matrix cores, so frac can exceed 1 -- the share of the MFMA peak actually executed is:
                          "executed_mfma_frac": (achieved / 2.25 / PEAK_FP32_MFMA_TFLOPS) if (a.dtype == "f32" and not a.train) else None},
-            "train": train_leg, "config0": config0,
+            "train": train_leg, "config0": config0, "collective": collective,
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(state, z0_cpu, t_cpu, a.method, a.cpu_seconds, rtol=solver.odeint_rtol, atol=solver.odeint_atol)

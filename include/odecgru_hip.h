@@ -314,7 +314,8 @@ size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int batch, int n
  * dense output at t[i].  The call returns after the controller has reported completion (it polls a pinned host
  * mailbox; it does not synchronise the stream otherwise).  stats_host[4] (may be NULL) = {nfe, n_accept, n_reject,
  * attempts enqueued}.  first_step > 0 is torchdiffeq's options={'first_step': dt} (skips the initial-step heuristic);
- * max_steps <= 0 means unlimited (torchdiffeq max_num_steps = 2^31-1).
+ * max_steps <= 0 means unlimited (torchdiffeq max_num_steps = 2^31-1); like torchdiffeq's it bounds the attempted steps (accepted
+ * or rejected) spent on ONE output time -- the counter is a local of `_advance(next_t)` and restarts with every output.
  * accepted_host (may be NULL): receives (t0, dt) of the accepted steps, in order, at most accepted_cap pairs -- the
  * input of odehip_odeint_dopri5_backward (stats_host[1] > accepted_cap means the log was cut).
  * Errors: ODEHIP_ENOTCONV (dt underflow / max_steps), ODEHIP_ENAN (non-finite error ratio). */
@@ -334,17 +335,6 @@ int odehip_odeint_dopri5_backward(const odehip_convstack* f, const odehip_convst
                                   int batch, const double* accepted_host, int n_steps, const float* z0_nchw,
                                   const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w, float* const* grad_b,
                                   void* workspace, size_t workspace_bytes, void* stream);
-
-/* ---- EXPERIMENTAL, not used by the entry points above: Winograd F(4x4,3x3) for the 64 -> 64 3x3 layers with the input
- * transform outside the matrix kernel (conv_f43.hip).  odehip_f43_transform_input turns a Q4 activation
- * (B,64,16,16) into the transformed form V (odehip_f43_input_floats(B) floats), odehip_pack_conv_weight_f43 a weight into U
- * (odehip_f43_weight_floats() floats), odehip_conv_f43 computes conv(+bias, +ReLU) from V and U into a Q4 tensor, n times
- * back to back (n = 1 for the layer itself; n > 1 for timing). */
-size_t odehip_f43_weight_floats(void);
-size_t odehip_f43_input_floats(int batch);
-int odehip_pack_conv_weight_f43(const float* w_oihw, float* u, int transpose_flip, void* stream);
-int odehip_f43_transform_input(const float* src_q4, float* v, int batch, void* stream);
-int odehip_conv_f43(const float* v, const float* u, const float* bias, float* dst_q4, int batch, int relu, int n, void* stream);
 
 /* ---- optimizer step of the training loop (train_test.py:24,205: optim.Adam(model.parameters(), lr)) ------------------------ */
 

@@ -126,12 +126,6 @@ SIGNATURES = {
                                                        ctypes.c_int, ctypes.c_void_p]),
     "odehip_debug_repeat_f": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p]),
-    "odehip_f43_weight_floats": (ctypes.c_size_t, []),
-    "odehip_f43_input_floats": (ctypes.c_size_t, [ctypes.c_int]),
-    "odehip_pack_conv_weight_f43": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "odehip_f43_transform_input": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "odehip_conv_f43": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_flags": (None, [ctypes.c_int]),
     "odehip_set_norm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_set_debug_buffer": (None, [ctypes.c_void_p]),
@@ -242,8 +236,10 @@ def check(rc):
     if rc == 0:
         code = _lib.odehip_persistent_error(1) if _lib is not None else 0
         if code:
-            raise OdeHipError(f"a persistent launch gave up waiting for a partner workgroup (code {code}): results of the call that "
-                              "was running are invalid (its outputs were filled with NaN); persistent launches are now disabled")
+            raise OdeHipError(f"a persistent launch of THIS OR AN EARLIER call gave up waiting for a partner workgroup (code {code}): the word is "
+                              "read without synchronising, so the kernel that set it may belong to any call enqueued since the last check.  "
+                              "Results since then are invalid (whole-trajectory launches NaN-fill their outputs; single-evaluation launches "
+                              "-- ODEHIP_PERSISTENT_SMALL=1 -- do not); persistent launches are now disabled for this process")
         return
     msg = load().odehip_last_error().decode("utf-8", "replace")
     if rc == -1:

@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256) void controller_kernel(DopriState* st, const f
     while (j < st->n_times && t_out[j] <= t1n) ++j;  // outputs inside (t0, t1]: `while next_t > t1` is false
     st->j_hi = j;
     st->j_next = j;
+    // torchdiffeq counts max_num_steps per `_advance(next_t)` call (a local of it): once this step has covered output j_lo the
+    // call returns, and the calls for the further outputs it covers take no step at all -- the next attempt starts a fresh count
+    if (j > st->j_lo) st->n_steps = 0;
   } else {
     st->n_reject += 1;
     st->j_lo = st->j_hi = st->j_next;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void controller_kernel(DopriState* st, const f
   const bool done = st->j_next >= st->n_times;
   if (!done) {
     if (!(st->t1 + dtn > st->t1)) status = ODEHIP_ENOTCONV;       // "underflow in dt"
-    if (st->n_steps >= st->max_steps) status = ODEHIP_ENOTCONV;    // max_num_steps
+    if (st->n_steps >= st->max_steps) status = ODEHIP_ENOTCONV;    // max_num_steps: attempts spent on the output time in progress
   }
   if (status) st->status = status;
   st->done = done || status != 0;

@@ -182,6 +182,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
   ODEHIP_REQUIRE(!(negate && save_for_backward), "odeint_fixed: backward through negated dynamics is not supported");
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(z0_nchw && out_nchw && workspace, "odeint_fixed: null pointer");
+  ODEHIP_REQUIRE(saved_format_out || !save_for_backward, "odeint_fixed: saved_format_out is required with save_for_backward");
   const FixedLayout L(f, batch, n_times, method, save_for_backward);
   ODEHIP_REQUIRE(workspace_bytes >= L.total, "odeint_fixed: workspace too small (%zu < %zu)", workspace_bytes, L.total);
   hipStream_t stream = (hipStream_t)stream_;
@@ -214,8 +215,7 @@ extern "C" int odehip_odeint_fixed(const odehip_convstack* f, int method, const 
     if (save_for_backward) {
       rc = launch_ftraj_bf16_saving(f, z0_nchw, out_nchw, hdev, n_times, batch, L.p(ws, L.off_xin), L.st, L.p(ws, L.off_hid),
                                     (size_t)L.NH * L.hid, L.hid, stream);
-      if (rc == ODEHIP_OK && saved_format_out) *saved_format_out = 1;
-      ODEHIP_REQUIRE(saved_format_out, "odeint_fixed: saved_format_out is required with save_for_backward");
+      if (rc == ODEHIP_OK) *saved_format_out = 1;   // non-null: checked with the arguments, before anything was enqueued
     } else {
       rc = launch_ftraj_bf16(f, method, z0_nchw, out_nchw, hdev, n_times, batch, negate, stream);
     }
@@ -366,15 +366,32 @@ extern "C" int odehip_odeint_fixed_backward(const odehip_convstack* f, const ode
     // and the weight gradients of a finished segment run on a library-owned SIDE STREAM, on the idle CUs, while the next segment
     // is swept.  The concurrent weight-gradient launches are sized to the CUs the sweep leaves free (one workgroup per sample at
     // 128 samples) so that they cannot take the CUs the sweep's next launch needs; the last segment's run on the whole chip.  dW accumulates over the segments in order.
-    static hipStream_t side = nullptr;
+    // The side stream and its events are library state of ONE device (one process per GPU is the deployment model): created once
+    // under a lock, bound to the device that was current then, and every later call must come from that device -- a call from
+    // another one is refused instead of launching the weight gradients on the wrong device's stream.  Calls are serialised by the
+    // caller (one host thread per process drives the library: SURVEY.md section 8b "Threading"); the lock only makes the lazy
+    // creation itself safe.
     constexpr int kMaxSeg = 4;   // measured at B=128, T=40: 4 segments 9.3 ms, 6: 9.4, 8: 9.6, uncut 10.2
+    static std::mutex side_mu;
+    static hipStream_t side = nullptr;
+    static int side_device = -1;
     static hipEvent_t ev_seg[kMaxSeg] = {}, ev_done = nullptr;
-    if (!side) {
-      int lo_pri = 0, hi_pri = 0;
-      ODEHIP_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-      ODEHIP_CHECK_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo_pri));   // the sweep's launches go first
-      for (int i = 0; i < kMaxSeg; ++i) ODEHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
-      ODEHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    {
+      std::lock_guard<std::mutex> lk(side_mu);
+      int cur_dev = -1;
+      ODEHIP_CHECK_HIP(hipGetDevice(&cur_dev));
+      if (!side) {
+        int lo_pri = 0, hi_pri = 0;
+        ODEHIP_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+        hipStream_t s_new = nullptr;
+        ODEHIP_CHECK_HIP(hipStreamCreateWithPriority(&s_new, hipStreamNonBlocking, lo_pri));   // the sweep's launches go first
+        for (int i = 0; i < kMaxSeg; ++i) ODEHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_seg[i], hipEventDisableTiming));
+        ODEHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+        side_device = cur_dev;
+        side = s_new;
+      }
+      ODEHIP_REQUIRE(cur_dev == side_device, "odeint_fixed_backward: the library's side stream belongs to device %d, this call runs on device %d "
+                                               "(one process drives one GPU)", side_device, cur_dev);
     }
     const int n_steps = n_times - 1;
     const int n_eval = n_steps * S;

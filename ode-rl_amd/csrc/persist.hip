@@ -113,7 +113,8 @@ void persist_count_launch() {
   ++g_persist.launches;
 }
 
-unsigned persist_error(bool clear) {
+// caller holds g_persist.mu
+static unsigned persist_error_locked(bool clear) {
   PersistState& P = g_persist;
   if (!P.host_err) return 0;
   const unsigned code = *P.host_err;
@@ -122,6 +123,11 @@ unsigned persist_error(bool clear) {
     P.enabled = 0;
   }
   return code;
+}
+
+unsigned persist_error(bool clear) {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  return persist_error_locked(clear);
 }
 
 PersistScope::PersistScope() : lock_(g_persist.mu, std::defer_lock) {}
@@ -224,7 +230,12 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
                                                   P.host_err_dev, kPersistGrid, stream);
         if (rcs == ODEHIP_OK) {
           ++P.launches;
-          return rcs;   // (small launches: epoch-tagged flag area, no guard -- their callers synchronise and check the host word)
+          // Small launches carry NO NaN guard: their flag area is epoch-tagged and shared, so there is no per-launch abort word a
+          // guard kernel could read.  Their callers (one evaluation of f, an input-gradient chain, the encoder's Euler step) are
+          // enqueue-only, so a give-up in one of them is reported LATE: the sticky host word is read by the binding at the next
+          // library call after the kernel has run (or by odehip_persistent_error), which raises "an earlier call ..." -- the data
+          // that earlier call returned is invalid.  This path is off by default (ODEHIP_PERSISTENT_SMALL=1 enables it).
+          return rcs;
         }
         P.enabled = 0;
         (void)hipGetLastError();
@@ -286,7 +297,6 @@ extern "C" int odehip_set_persistent_trajectory(int enable) {
 }
 
 extern "C" int odehip_persistent_error(int clear) {
-  std::lock_guard<std::mutex> g(g_persist.mu);
   return (int)persist_error(clear != 0);
 }
 

@@ -14,8 +14,26 @@ from . import _lib
 _workspaces = {}
 
 
+_last_stream = None   # the stream the library's process-global state (workspace caches, flag areas, layer tables) was last used on
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The caller's current stream, handed to the C ABI.  The library's state is process-global (ONE
+    process per GPU, one stream at a time): calls on a second DEVICE are refused, and when the current stream CHANGES the new
+    stream first waits for everything enqueued on the previous one, so two streams can never run library launches that share a
+    workspace or flag area concurrently.  (Under graph capture the wait cannot be expressed -- an event from outside the capture
+    -- and the capturing caller has ordered its streams itself.)"""
+    global _last_stream
+    cur = torch.cuda.current_stream()
+    if _last_stream is None:
+        _last_stream = cur
+    elif cur != _last_stream:
+        if cur.device != _last_stream.device:
+            raise RuntimeError(f"ode_rl_amd drives ONE GPU per process: first used on {_last_stream.device}, now called on {cur.device}")
+        if not torch.cuda.is_current_stream_capturing():
+            cur.wait_stream(_last_stream)
+        _last_stream = cur
+    return ctypes.c_void_p(cur.cuda_stream)
 
 
 def _ptr(t):
@@ -261,35 +279,6 @@ def _bf16_cell_ok(cell_input, hidden, ks):
 
 def _bf16_ok(cin, cout, ks):
     return ks == 3 and cin % 16 == 0 and cin <= 128 and cin // 16 in (1, 2, 4, 8) and cout % 32 == 0
-
-
-# ---- experimental F(4x4,3x3) path (csrc/conv_f43.hip): building blocks only, not used by the solver entry points yet
-def f43_pack_weight(w, transpose_flip=False):
-    require_device_tensor(w, "weight")
-    w = w.detach().contiguous()
-    if tuple(w.shape) != (64, 64, 3, 3):
-        raise ValueError("the F(4x4,3x3) prototype serves 64 -> 64 3x3 layers only")
-    lib = _lib.load()
-    u = torch.empty(lib.odehip_f43_weight_floats(), dtype=torch.float32, device=w.device)
-    _lib.check(lib.odehip_pack_conv_weight_f43(_ptr(w), _ptr(u), int(bool(transpose_flip)), _stream()))
-    return u
-
-
-def f43_transform_input(x_q4):
-    require_device_tensor(x_q4, "x")
-    b = x_q4.shape[0]
-    if tuple(x_q4.shape) != (b, 16, 256, 4):
-        raise ValueError("f43_transform_input needs a Q4 tensor of 64 channels")
-    lib = _lib.load()
-    v = torch.empty(lib.odehip_f43_input_floats(b), dtype=torch.float32, device=x_q4.device)
-    _lib.check(lib.odehip_f43_transform_input(_ptr(x_q4.contiguous()), _ptr(v), b, _stream()))
-    return v
-
-
-def f43_conv(v, u, bias, batch, relu=False, repeat=1):
-    out = torch.empty((batch, 16, 256, 4), dtype=torch.float32, device=v.device)
-    _lib.check(_lib.load().odehip_conv_f43(_ptr(v), _ptr(u), _ptr(bias), _ptr(out), batch, int(bool(relu)), int(repeat), _stream()))
-    return out
 
 
 USE_WINOGRAD = os.environ.get("ODEHIP_NO_WINOGRAD") is None   # 3x3 layers with cin % 16 == 0 run the Winograd kernel (2.25x fewer MFMAs, still exact-fp32 arithmetic)

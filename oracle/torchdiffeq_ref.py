@@ -227,9 +227,10 @@ def _integrate_dopri5(func, y0, t, rtol, atol, stats, norm, options=None):
         stats["nfe"] = stats.get("nfe", 0) + 1
     y, f, t0, t1 = y0, f0, t[0], t[0]
     interp = [y0] * 5
-    n_steps = 0
     for i in range(1, len(t)):
         next_t = t[i]
+        n_steps = 0   # torchdiffeq 0.2.1 solvers.py `_advance(next_t)`: the counter is a LOCAL of the call -- max_num_steps bounds the
+        #               attempted steps (accepted or rejected) spent on ONE output time, not the whole integration
         while next_t > t1:
             assert n_steps < max_num_steps, "max_num_steps exceeded ({}>={})".format(n_steps, max_num_steps)
             ta = t1
@@ -251,6 +252,7 @@ def _integrate_dopri5(func, y0, t, rtol, atol, stats, norm, options=None):
                 stats["n_reject"] = stats.get("n_reject", 0) + 1
             dt = _optimal_step_size(dt, ratio)
             n_steps += 1
+        stats.setdefault("steps_per_output", []).append(n_steps)   # (test instrumentation) attempts this `_advance` call took
         solution[i] = _interp_evaluate(interp, t0, t1, next_t)
     return solution
 

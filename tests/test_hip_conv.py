@@ -138,20 +138,3 @@ def test_winograd5_conv_matches_torch(cuda, b, cin1, cin2, cout, relu):
     dg = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(gy.to(cuda)), hip_ops.pack_conv_weight(wd, transpose_flip=True), None,
                                             cin, 5, w_wino=hip_ops.pack_conv_weight_winograd5(wd, transpose_flip=True)))
     assert rel_l2(dg, xr.grad) <= 1e-5
-
-
-@pytest.mark.parametrize("b,relu", [(3, True), (1, False)])
-def test_experimental_f43_conv_matches_torch(cuda, b, relu):
-    """Winograd F(4x4,3x3) prototype (conv_f43.hip): input transform kernel + K-split matrix kernel against
-    torch's conv2d.  fp32 F(4x4,3x3) carries ~2e-6 rel-L2 per layer (tools/experiments/winograd_f43_error.py): tolerance 1e-5."""
-    from ode_rl_amd import hip_ops
-    torch.manual_seed(b)
-    x = torch.randn(b, 64, 16, 16, device=cuda) * 0.5
-    w = torch.randn(64, 64, 3, 3, device=cuda) / 24
-    bias = torch.randn(64, device=cuda)
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
-    if relu:
-        ref = torch.relu(ref)
-    v = hip_ops.f43_transform_input(hip_ops.nchw_to_q4(x))
-    out = hip_ops.q4_to_nchw(hip_ops.f43_conv(v, hip_ops.f43_pack_weight(w), bias, b, relu=relu))
-    assert rel_l2(out, ref) <= 1e-5

@@ -151,3 +151,23 @@ def test_adjoint_matches_autograd_through_the_solver():
     torch.testing.assert_close(gy0, g[0], rtol=1e-6, atol=1e-8)
     for a, b in zip(gp, g[1:]):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
+
+
+def test_max_num_steps_bounds_the_steps_of_one_output_time_not_of_the_integration():
+    """torchdiffeq 0.2.1 `AdaptiveStepsizeODESolver`-style `_advance(next_t)` (solvers.py / rk_common.py): `n_steps = 0` is a local
+    of the call and `assert n_steps < self.max_num_steps` guards each step of THAT call ("one deviation").  A grid whose
+    outputs each need a few steps tells the two readings apart: the whole integration takes more attempts than any one output."""
+    f = lambda t, y: -3.0 * y * (1.0 + 0.5 * torch.sin(7.0 * t))
+    y0 = torch.tensor([1.0, 2.0], dtype=torch.float64)
+    t = torch.linspace(0.0, 4.0, 9, dtype=torch.float64)
+    st = {}
+    ref = td.odeint(f, y0, t, rtol=1e-7, atol=1e-9, method="dopri5", stats=st)
+    per_out = st["steps_per_output"]
+    assert len(per_out) == 8 and sum(per_out) == st["n_accept"] + st.get("n_reject", 0)
+    worst = max(per_out)
+    assert worst >= 2 and sum(per_out) > worst + 2, per_out        # the input separates the two semantics
+    # bound == the worst single output: passes under torchdiffeq's per-call counter (a whole-integration counter would assert)
+    got = td.odeint(f, y0, t, rtol=1e-7, atol=1e-9, method="dopri5", options={"max_num_steps": worst})
+    assert torch.equal(got, ref)
+    with pytest.raises(AssertionError, match="max_num_steps exceeded"):
+        td.odeint(f, y0, t, rtol=1e-7, atol=1e-9, method="dopri5", options={"max_num_steps": worst - 1})

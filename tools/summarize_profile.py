@@ -47,6 +47,15 @@ def main():
     else:
         notes.update({"algorithmic_bytes_per_launch": 8536064, "algorithmic_flop_per_launch": 1207959552,
                       "executed_mfma_flop_per_launch": 536870912})
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    notes["source_sha256"] = bench.source_digest()      # bench.py reports `traffic` only while the kernel sources still match
+    notes["source_files"] = list(bench.TRAFFIC_SOURCES)
+    try:
+        notes["git_head"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        notes["git_head"] = None
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         notes["hbm_bytes_per_launch"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
     out = {"forward_kernel_stats": stats(fwd)[:12], "train_kernel_stats": stats(trn)[:16], "pmc_dominant_kernel_per_launch": pmc,
