@@ -33,10 +33,71 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, float c, f32x4 o) {
   return f32x4{__builtin_fmaf(a.x, c, o.x), __builtin_fmaf(a.y, c, o.y), __builtin_fmaf(a.z, c, o.z), __builtin_fmaf(a.w, c, o.w)};
 }
 
+
+// ---- order-1 stage combine (CombineArgs::order == 1; the adaptive solver's drivers) of one channel quad of one pixel.  Split in
+// two so that the adaptive persistent walk can run the first half ahead of the matrix work; emit_quad / epilogue() run both back to
+// back.  Every multiply-add is an explicit fma: all kernels round alike.
+struct CombinePartial {
+  f32x4 sa, sb, se;   // sums over k_prev of c1 / c2 / ce
+};
+__device__ __forceinline__ CombinePartial combine1_prev(const CombineArgs& m, size_t off) {
+  CombinePartial p;
+  p.sa = p.sb = p.se = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < m.n_prev; ++j) {
+    const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
+    p.sa = fma4(kp, m.c1[j], p.sa);
+    p.sb = fma4(kp, m.c2[j], p.sb);
+    p.se = fma4(kp, m.ce[j], p.se);
+  }
+  return p;
+}
+// error-norm contribution of one quad: err = h * se, tol = atol + rtol * max(|y|, |y1|)
+__device__ __forceinline__ float combine1_err(f32x4 se, float h, f32x4 yv, f32x4 y1, float rtol, float atol, float esum) {
+  const f32x4 e = se * h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float tol = __builtin_fmaf(rtol, fmaxf(fabsf(yv[i]), fabsf(y1[i])), atol);
+    const float r = e[i] / tol;
+    esum = __builtin_fmaf(r, r, esum);
+  }
+  return esum;
+}
+__device__ __forceinline__ void combine1_tail(const CombineArgs& m, int b, int qout, int Q, int P, size_t off, f32x4 kc, f32x4 yv, float h,
+                                              CombinePartial p, float& esum, float* nchw) {
+  const int n = m.n_prev;
+  if (m.out1) *(f32x4*)(m.out1 + off) = fma4(fma4(kc, m.c1[n], p.sa), h, yv);
+  if (m.out2 || nchw) {
+    const f32x4 o2 = fma4(fma4(kc, m.c2[n], p.sb), h, yv);
+    if (m.out2) *(f32x4*)(m.out2 + off) = o2;
+    if (nchw) {
+      float* o = nchw + ((size_t)b * qout * 4 + Q * 4) * kPix + P;
+      o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+    }
+  }
+  if (m.err_partials) esum = combine1_err(fma4(kc, m.ce[n], p.se), h, yv, *(const f32x4*)(m.err_y1 + off), m.rtol, m.atol, esum);
+}
+
+// ---- elementwise row (ConvArgs::combine == 4) on one quad: out = (y ? y : 0) + sum_j (c[j] * hs) * k_prev[j], explicit fmas
+__device__ __forceinline__ void ew_quad(const CombineArgs& m, size_t off, float hs) {
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+  if (m.y) s1 = *(const f32x4*)(m.y + off);
+  f32x4 s2 = s1;
+  for (int j = 0; j < m.n_prev; ++j) {
+    const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
+    s1 = fma4(kp, m.c1[j] * hs, s1);
+    if (m.out2) s2 = fma4(kp, m.c2[j] * hs, s2);
+  }
+  if (m.out1) *(f32x4*)(m.out1 + off) = s1;
+  if (m.out2) *(f32x4*)(m.out2 + off) = s2;
+}
+
 // ---- per-(channel quad Q, pixel P) epilogue: plain / ReLU store, Runge-Kutta stage combine (+ adaptive error
 // partial), ReLU-mask backward, reverse-sweep targets.  `v` is the conv output (bias included) of 4 channels.
 // nchw_override: persistent trajectory kernel only -- where this layer's NCHW result frame goes (its table cannot hold the
 // pointer: the output tensor changes from call to call)
+// ORDER1 = false: instantiations that can never meet an order-1 stage combine (the fixed-grid persistent walks: tables with such rows
+// go to the adaptive walk) leave the branch out -- its uniform operands would otherwise cost the headline kernel scalar registers
+template <bool ORDER1 = true>
 __device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P, f32x4 v, float& esum, float* nchw_override = nullptr) {
   const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
   if (a.combine == 0) {
@@ -73,6 +134,13 @@ __device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P
   const float h = m.h_ptr ? *m.h_ptr : 1.0f;
   const f32x4 kc = v * m.k_scale;
   if (m.k_out) *(f32x4*)(m.k_out + off) = kc;
+  if constexpr (ORDER1) {
+    if (m.y && m.order) {
+      combine1_tail(m, b, a.qout, Q, P, off, kc, *(const f32x4*)(m.y + off), h, combine1_prev(m, off), esum,
+                    nchw_override ? nchw_override : m.out2_nchw);
+      return;
+    }
+  }
   if (m.y) {
     const f32x4 yv = *(const f32x4*)(m.y + off);
     f32x4 sa = kc * m.c1[m.n_prev];
@@ -225,6 +293,10 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
     f32x4 kc = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
     kc *= m.k_scale;
     if (m.k_out) *(f32x4*)(m.k_out + off) = kc;
+    if (m.y && m.order) {
+      combine1_tail(m, b, a.qout, Q, P, off, kc, *(const f32x4*)(m.y + off), h, combine1_prev(m, off), esum, m.out2_nchw);
+      continue;
+    }
     if (m.y) {
       const f32x4 yv = *(const f32x4*)(m.y + off);
       f32x4 sa = kc * m.c1[m.n_prev];

@@ -390,6 +390,21 @@ unsigned long long* g_debug_buf = nullptr;
 
 thread_local ConvRecorder* g_conv_recorder = nullptr;
 
+// an elementwise row (ConvArgs::combine == 4) outside a persistent walk: the same fma sequence per element (ew_quad)
+__global__ __launch_bounds__(256) void ew_row_kernel(const ConvArgs a, long long n_quads) {
+  if (a.skip && *a.skip) return;
+  const float hs = a.cmb.h_ptr ? *a.cmb.h_ptr : 1.0f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_quads; i += (long long)gridDim.x * 256) ew_quad(a.cmb, (size_t)i * 4, hs);
+}
+int launch_ew_row(const ConvArgs& a, hipStream_t stream) {
+  ODEHIP_REQUIRE(a.batch > 0 && a.qout > 0 && (a.cmb.out1 || a.cmb.out2) && a.cmb.n_prev >= 0 && a.cmb.n_prev <= ODEHIP_MAX_STAGES,
+                 "elementwise row: bad arguments");
+  const long long n_quads = (long long)a.batch * a.qout * kPix;
+  hipLaunchKernelGGL(ew_row_kernel, dim3((unsigned)((n_quads + 255) / 256 < 2048 ? (n_quads + 255) / 256 : 2048)), dim3(256), 0, stream, a, n_quads);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
 int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
   if (g_conv_recorder) {
     ConvRecorder* r = g_conv_recorder;
@@ -397,6 +412,7 @@ int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
     r->items[r->count++] = a_in;
     return ODEHIP_OK;
   }
+  if (a_in.combine == 4) return launch_ew_row(a_in, stream);
   ConvArgs a = a_in;
   a.debug = g_debug_flags;
   a.dbg = g_debug_buf;

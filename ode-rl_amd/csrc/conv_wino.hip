@@ -101,7 +101,10 @@ __device__ __forceinline__ void wait_done(const PersistHook& hk, int sel_mask = 
 // the first weight chunk is requested BEFORE waiting for the partners, and finished output is announced through hk.done.
 // QOUT: output channel quads of the layer as the PERSIST epilogue's prefetched operands are addressed (16 = 64 channels; the
 // per-launch kernel goes through emit_quad, which reads a.qout)
-template <int NCHUNK, bool DBG, bool PERSIST, int QOUT = 16>
+// ADAPT (with PERSIST): the walk of the adaptive solver's tables (wino_persist_d_kernel) -- every epilogue's operands are reduced at
+// the START of the layer to at most four quads per output pixel (a stage combine of any depth becomes y, the two partial sums over
+// the earlier stages and y1; reverse-sweep targets up to two (srcA, srcB) pairs), the step size may live on the device.
+template <int NCHUNK, bool DBG, bool PERSIST, int QOUT = 16, bool ADAPT = false>
 __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, const float* __restrict__ p_u, int p_qin, const ConvArgs& a,
                                            int b, int ct, int rh, char* smem, const PersistHook& hk) {
   static_assert(!PERSIST || (NCHUNK % 2 == 0), "the layer-to-layer LDS hand-over assumes an even chunk count");
@@ -282,7 +285,90 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
   bool e_y = false;
   float e_h = 1.0f, e_ks = 1.0f, e_c1c = 0.0f, e_c2c = 0.0f, e_c1[3] = {0.f, 0.f, 0.f}, e_c2[3] = {0.f, 0.f, 0.f};
   f32x4 e_yv[4], e_kv[3][4];
-  if (PERSIST) {
+  // ---- ADAPT: the reduced operand set (see the template comment)
+  int d_kind = 0;   // 0 plain / ReLU store; 1 stage combine (order 1); 2 ReLU-mask backward; 3 reverse-sweep targets (<= 2, constant
+                    // coefficients) held in registers; 5 anything else: the shared epilogue reads the table after the matrix work
+  f32x4 d_y[4], d_y1[4], d_sa[4], d_sb[4];
+  float d_h = 1.0f, d_ks = 1.0f, d_cA = 0.0f, d_cB = 0.0f, d_rtol = 0.0f, d_atol = 0.0f, d_t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float* d_o[4] = {nullptr, nullptr, nullptr, nullptr};   // kind 1: k_out, out1, out2, nchw frame; kind 3: target outputs 0, 1
+  bool d_has_y = false, d_err = false, d_f[4] = {false, false, false, false};
+  if constexpr (ADAPT) {
+    typedef const __attribute__((address_space(4))) float ConstF;
+    e_relu = a.relu;
+    e_dst = a.dst;
+    d_kind = a.combine == 0 ? 0 : 5;
+    if (a.combine == 2) {
+      const BwdArgs& w = a.bwd;
+      const float hb = a.h_by_value ? a.cmb.atol : (w.h_ptr ? *(ConstF*)w.h_ptr : 0.0f);
+      d_ks = w.sc_c + w.sc_h * hb;
+      d_has_y = w.mask_src != nullptr;
+      d_kind = 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+        if (d_has_y) d_y[q] = *(const f32x4*)(w.mask_src + off);
+      }
+    } else if (a.combine == 3 && a.bwd.n_targets <= 2 && !a.bwd.h_ptr) {
+      const BwdArgs& w = a.bwd;
+      d_kind = 3;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t < w.n_targets) {
+          const BwdTarget& T = w.tgt[t];
+          d_o[t] = T.out;
+          d_t[3 * t] = T.g_c; d_t[3 * t + 1] = T.a_c; d_t[3 * t + 2] = T.b_c;
+          d_f[2 * t] = T.srcA != nullptr; d_f[2 * t + 1] = T.srcB != nullptr;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+            if (t == 0) {
+              if (d_f[0]) d_y[q] = *(const f32x4*)(T.srcA + off);
+              if (d_f[1]) d_y1[q] = *(const f32x4*)(T.srcB + off);
+            } else {
+              if (d_f[2]) d_sa[q] = *(const f32x4*)(T.srcA + off);
+              if (d_f[3]) d_sb[q] = *(const f32x4*)(T.srcB + off);
+            }
+          }
+        }
+      }
+    } else if (a.combine == 1 && (a.cmb.order == 1 || !a.cmb.y) && !(a.cmb.err_partials && (a.cmb.out2 || a.cmb.out2_nchw || a.dbg))) {
+      const CombineArgs& m = a.cmb;
+      d_kind = 1;
+      const int np = m.n_prev;
+      d_h = a.h_by_value ? m.atol : (m.h_ptr ? *(ConstF*)m.h_ptr : 1.0f);
+      d_ks = m.k_scale;
+      d_err = m.err_partials != nullptr;
+      d_has_y = m.y != nullptr;
+      d_cA = m.c1[np];
+      d_cB = d_err ? m.ce[np] : m.c2[np];
+      d_rtol = m.rtol; d_atol = m.atol;
+      d_o[0] = m.k_out; d_o[1] = m.out1; d_o[2] = m.out2;
+      d_o[3] = a.dbg ? hk.nchw_base + ((size_t)a.dbg - 1) : m.out2_nchw;
+      const bool needB = d_err || d_o[2] || d_o[3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d_sa[q] = d_sb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d_has_y) {
+          const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+          d_y[q] = *(const f32x4*)(m.y + off);
+          if (d_err) d_y1[q] = *(const f32x4*)(m.err_y1 + off);
+        }
+      }
+      if (d_has_y) {
+        for (int j = 0; j < np; ++j) {   // the sums over the earlier stages, in the order of combine1_prev (conv_common.h)
+          const float* kp = m.k_prev[j];
+          const float cA = m.c1[j], cB = d_err ? m.ce[j] : m.c2[j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+            const f32x4 kv = *(const f32x4*)(kp + off);
+            d_sa[q] = fma4(kv, cA, d_sa[q]);
+            if (needB) d_sb[q] = fma4(kv, cB, d_sb[q]);
+          }
+        }
+      }
+    }
+  } else if (PERSIST) {
     e_combine = a.combine;
     e_relu = a.relu;
     e_dst = a.dst;
@@ -399,7 +485,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       return;
     }
     if (e_combine == 3) {  // reverse-sweep targets: the shared epilogue, read from the table
-      emit_quad(a, b, Q, P, v, esum);
+      emit_quad<false>(a, b, Q, P, v, esum);
       return;
     }
     const f32x4 kc = v * e_ks;
@@ -428,12 +514,64 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       }
     }
   };
+  // ADAPT: the same arithmetic as emit_quad's (order 1 for stage combines), on the operands reduced at the start of the layer
+  auto emit_adapt = [&](int q, int P, f32x4 v) {
+    const size_t off = (((size_t)b * QOUT + Q) * kPix + P) * 4;
+    if (d_kind == 0) {
+      if (e_relu) {
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+      }
+      *(f32x4*)(e_dst + off) = v;
+    } else if (d_kind == 2) {
+      v *= d_ks;
+      if (d_has_y) {
+        const f32x4 mk = d_y[q];
+        v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f;
+        v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+      }
+      *(f32x4*)(e_dst + off) = v;
+    } else if (d_kind == 1) {
+      const f32x4 kc = v * d_ks;
+      if (d_o[0]) *(f32x4*)(d_o[0] + off) = kc;
+      if (d_has_y) {
+        if (d_o[1]) *(f32x4*)(d_o[1] + off) = fma4(fma4(kc, d_cA, d_sa[q]), d_h, d_y[q]);
+        if (d_err) {
+          esum = combine1_err(fma4(kc, d_cB, d_sb[q]), d_h, d_y[q], d_y1[q], d_rtol, d_atol, esum);
+        } else if (d_o[2] || d_o[3]) {
+          const f32x4 o2 = fma4(fma4(kc, d_cB, d_sb[q]), d_h, d_y[q]);
+          if (d_o[2]) *(f32x4*)(d_o[2] + off) = o2;
+          if (d_o[3]) {
+            float* o = d_o[3] + ((size_t)b * (QOUT * 4) + Q * 4) * kPix + P;
+            o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+          }
+        }
+      }
+    } else if (d_kind == 3) {
+      if (d_o[0]) {
+        f32x4 o = v * d_t[0];
+        if (d_f[0]) o = fma4(d_y[q], d_t[1], o);
+        if (d_f[1]) o = fma4(d_y1[q], d_t[2], o);
+        *(f32x4*)(d_o[0] + off) = o;
+      }
+      if (d_o[1]) {
+        f32x4 o = v * d_t[3];
+        if (d_f[2]) o = fma4(d_sa[q], d_t[4], o);
+        if (d_f[3]) o = fma4(d_sb[q], d_t[5], o);
+        *(f32x4*)(d_o[1] + off) = o;
+      }
+    } else {
+      emit_quad(a, b, Q, P, v, esum, a.dbg ? hk.nchw_base + ((size_t)a.dbg - 1) : nullptr);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const f32x4 y0 = S[i][0] + S[i][1] + S[i][2] + bias4;
     const f32x4 y1 = pk_sub(pk_sub(S[i][1] + bias4, S[i][2]), S[i][3]);
     const int P = (r0 + 2 * oty + i) * 16 + 2 * otx;
-    if (PERSIST) {
+    if constexpr (ADAPT) {
+      emit_adapt(2 * i, P, y0);
+      emit_adapt(2 * i + 1, P + 1, y1);
+    } else if (PERSIST) {
       emit_pre(2 * i, P, y0);
       emit_pre(2 * i + 1, P + 1, y1);
     } else {
@@ -502,8 +640,32 @@ struct PersistArgs {
   int sleep6_combine;     // added in front of a layer whose input comes out of a stage-combine epilogue
   unsigned epoch;         // 0: the flag area was zeroed for this launch; else the flags persist across launches and every word is
                           // tagged with the epoch of the launch that wrote it (flag = epoch << 10 | layers done; xcc = epoch << 4 | id)
+  const int* n_layers_ptr;  // adaptive walk only: if non-null the number of rows to walk is read from the device (a table that a
+                            // device-side controller wrote for this launch); n_layers is then the capacity
 };
 
+// An elementwise row of the adaptive walk (ConvArgs::combine == 4, odehip_internal.h).  Only the consumer waves work, each lane on
+// the four quads the conv epilogues give it (channel quad Q of its 2x2 output tile): whatever it reads was written by this very
+// lane (or before the launch), so there is nothing to wait for; the row is then announced like a layer.
+template <int QOUT>
+__device__ __forceinline__ void ew_row(const ConvArgs& a, int b, int ct, int rh, const PersistHook& hk) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave >= 4) return;
+  typedef const __attribute__((address_space(4))) float ConstF;
+  const CombineArgs& m = a.cmb;
+  const float hs = m.h_ptr ? *(ConstF*)m.h_ptr : 1.0f;
+  const int ch = wave >> 1, thh = wave & 1, i16 = lane & 15, kq = lane >> 4;
+  const int Q = ct * 8 + ch * 4 + kq, tile = thh * 16 + i16, oty = tile >> 3, otx = tile & 7, r0 = rh * 8;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ew_quad(m, (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4, hs);
+  wait_vmcnt<0>();
+  if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(hk.done + hk.word0 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+template <bool ADAPT>
 __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvArgs* table) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nwg = gridDim.x;  // a multiple of 32: every XCD holds whole groups of 4
@@ -533,6 +695,14 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
     if (skip && *(ConstI*)skip) return;
   }
   const int n_groups = nwg >> 2;
+  int n_layers = pa.n_layers;
+  if constexpr (ADAPT) {
+    typedef const __attribute__((address_space(4))) int ConstI;
+    if (pa.n_layers_ptr) {
+      const int n_dev = *(ConstI*)pa.n_layers_ptr;
+      n_layers = n_dev < n_layers ? n_dev : n_layers;
+    }
+  }
   // A group walks TWO samples at a time, layer by layer in turn (when the batch gives it more than one): the hand-off latency of
   // one sample's layer (stores acknowledged -> flags seen -> next input tile loaded) is then covered by the other sample's layer.
   for (int b = group; b < pa.batch; b += 2 * n_groups) {
@@ -543,14 +713,14 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
     const float* src = table[0].src1;
     const float* u = table[0].w_wino;
     int prev_combine = 0;  // the layer whose output this one waits for ended in a Runge-Kutta stage combine (a longer epilogue)
-    for (int l = 0; l < pa.n_layers; ++l) {
+    for (int l = 0; l < n_layers; ++l) {
       // the table is constant for the whole launch: address space 4 lets the compiler fetch its fields with SCALAR loads (as a
       // plain global pointer they become vector loads, each followed by vmcnt(0), because the kernel also stores to global memory)
       typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
       const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
       const float* src_next = src;
       const float* u_next = u;
-      if (l + 1 < pa.n_layers) {
+      if (l + 1 < n_layers) {
         src_next = table[l + 1].src1;
         u_next = table[l + 1].w_wino;
         if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
@@ -564,7 +734,12 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
                                 pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0)};
-        wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
+        if constexpr (ADAPT) {
+          if (a.combine == 4) ew_row<16>(a, bs, ct, rh, hk);
+          else wino_layer<4, false, true, 16, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
+        } else {
+          wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
+        }
       }
       prev_combine = a.combine;
       src = src_next;
@@ -573,7 +748,12 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
   }
 }
 
-__global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs pa) { persist_walk(pa, pa.table); }
+__global__ __launch_bounds__(512, 1) void wino_persist_kernel(const PersistArgs pa) { persist_walk<false>(pa, pa.table); }
+
+// The walk of the adaptive solver's tables (dopri5 attempts, the backward passes of dopri5, the adaptive adjoint): stage combines of
+// any depth with the step size on the device, elementwise rows, reverse-sweep targets -- a separate kernel so that the fixed-grid
+// headline's instantiation above is not touched by any of it.
+__global__ __launch_bounds__(512, 1) void wino_persist_d_kernel(const PersistArgs pa) { persist_walk<true>(pa, pa.table); }
 
 // ---- the same walk for stacks with 128-channel ends (VidODE's dynamics 128 -> 64 -> 64 -> 128; helpers/utils.py:158-183 with
 // n_inputs = n_outputs = 128, n_units = 64): still four workgroups per sample.  A 128 -> 64 layer is eight input chunks; a
@@ -660,7 +840,7 @@ __global__ __launch_bounds__(512, 1) void wino_persist_small_kernel(const SmallP
   // the argument block itself is the table (constant address space: scalar loads, no private copy)
   typedef const __attribute__((address_space(4))) char ConstC;
   ConstC* base = (ConstC*)__builtin_amdgcn_kernarg_segment_ptr();
-  persist_walk(sa.pa, (const ConvArgs*)(const void*)(base + offsetof(SmallPersistArgs, layers)));
+  persist_walk<false>(sa.pa, (const ConvArgs*)(const void*)(base + offsetof(SmallPersistArgs, layers)));
 }
 
 template <int NCHUNK>
@@ -686,15 +866,19 @@ static int launch_wino_n(const ConvArgs& a, hipStream_t stream) {
 }
 
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                        float* out_nchw, int grid, hipStream_t stream, bool wide) {
+                        float* out_nchw, int grid, hipStream_t stream, bool wide, bool adaptive, const int* n_layers_ptr) {
   static bool attr_set = false;
+  ODEHIP_REQUIRE(!(wide && adaptive) && (adaptive || !n_layers_ptr), "wino_persist: no adaptive walk for 128-channel-ended stacks");
   if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     // every workgroup must be resident at once: one per CU (160 KiB of LDS each), `grid` <= number of CUs (checked by the caller)
     int per_cu = 0;
     ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist_kernel, 512, kWinoLds));
     ODEHIP_REQUIRE(per_cu >= 1, "wino_persist: the kernel does not fit a CU");
+    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist_d_kernel, 512, kWinoLds));
+    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist: the adaptive kernel does not fit a CU");
     attr_set = true;
   }
   PersistArgs pa;
@@ -706,10 +890,12 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   static const int sleep6c = [] { const char* e = getenv("ODEHIP_PERSIST_SLEEP_COMBINE"); return e ? atoi(e) : 4; }();  // sweep: 0: 1.382, 4: 1.367, 6: 1.370, 8: 1.383, 12: 1.404 ms
   pa.sleep6_combine = sleep6c;
   pa.epoch = 0;  // the caller zeroed the flag area
+  pa.n_layers_ptr = n_layers_ptr;
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
-  if (wide) hipLaunchKernelGGL(wino_persist_v_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
-  else      hipLaunchKernelGGL(wino_persist_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  if (wide)          hipLaunchKernelGGL(wino_persist_v_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  else if (adaptive) hipLaunchKernelGGL(wino_persist_d_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
+  else               hipLaunchKernelGGL(wino_persist_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }
@@ -729,6 +915,7 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
   memset(&sa, 0, sizeof(sa));
   sa.pa.table = nullptr; sa.pa.n_layers = n_layers; sa.pa.batch = batch; sa.pa.done = done; sa.pa.xcc_of = xcc_of;
   sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.sleep6 = 5; sa.pa.sleep6_combine = 4; sa.pa.epoch = epoch;
+  sa.pa.n_layers_ptr = nullptr;
   for (int i = 0; i < n_layers; ++i) sa.layers[i] = items[i];
   hipLaunchKernelGGL(wino_persist_small_kernel, dim3(grid), dim3(512), kWinoLds, stream, sa);
   ODEHIP_CHECK_HIP(hipGetLastError());

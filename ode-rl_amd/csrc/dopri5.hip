@@ -520,6 +520,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
     for (int s = 2; s <= 7; ++s) {  // k_s = f(x_s); fused: x_{s+1} = y + h*sum beta_{s+1,j} k_j   (s = 7: error norm)
       memset(&c, 0, sizeof(c));
       c.k_scale = ksc;
+      c.order = all_64(f);   // 64-channel stacks: the adaptive walk (stage sums formed ahead of the matrix work), same bits per layer
       c.y = y;
       c.h_ptr = &state->h;
       c.n_prev = s - 1;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "odehip_internal.h"
+#include "persist.h"
 
 namespace odehip {
 
@@ -27,27 +28,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 
-// out = (accumulate ? out : 0) + sum_j c[j] * src[j]
-struct MultiAxpy {
-  const float* src[8];
-  float c[8];
-  int n, accumulate;
-  float* out;
-};
-__global__ __launch_bounds__(256) void multi_axpy_kernel(MultiAxpy a, long long n4) {
-  for (long long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (a.accumulate) s = ((const f32x4*)a.out)[i];
-    for (int j = 0; j < a.n; ++j) s += ((const f32x4*)a.src[j])[i] * a.c[j];
-    ((f32x4*)a.out)[i] = s;
-  }
-}
-
-
 struct BwdLayout {
   int T, B, C, NH, N;
   size_t st, hid, slot_bytes;
-  size_t off_h, off_ping, off_pong, off_go, off_k, off_gY, off_gy, off_gk1, off_slots, off_tab, off_slab, total;
+  size_t off_h, off_ping, off_pong, off_go, off_k, off_gY, off_gy, off_gk1, off_slots, off_tab, off_psync, off_slab, total;
   BwdLayout(const odehip_convstack* f, int batch, int n_times, int n_steps) {
     T = n_times; B = batch; C = f->channels[0]; NH = f->n_convs - 1; N = n_steps;
     st = al256((size_t)B * C * kPix * 4);
@@ -66,7 +50,8 @@ struct BwdLayout {
     off_gy = take(2 * st);
     off_gk1 = take(2 * st);
     off_slots = take((size_t)(N > 0 ? N : 1) * slot_bytes);
-    off_tab = take(((size_t)N * 6 + 1) * sizeof(WgradPair));
+    off_tab = take(((size_t)N * 6 + 1) * sizeof(WgradPair) * ODEHIP_MAX_LAYERS);
+    off_psync = take(persist_sync_bytes(B));
     off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
     total = o;
   }
@@ -112,7 +97,6 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
   void* ws = workspace;
   const int NH = L.NH, NL = f->n_convs, N = n_steps;
   const size_t st_b = (size_t)batch * L.C * kPix * 4;
-  const long long n4 = (long long)(st_b / 16);
 
   // the log must tile [t[0], >= t[T-1]] without gaps, as the controller produced it
   std::vector<int> j_lo(N + 1), j_hi(N + 1);
@@ -157,64 +141,85 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
     if ((rc = upload_floats(hdev, hs.data(), N, stream)) != ODEHIP_OK) return rc;
   }
 
+  // Everything below is a sequence of ROWS -- conv layers with fused epilogues and elementwise rows (ConvArgs::combine == 4) --
+  // recorded by one PersistScope: ONE launch of the adaptive persistent walk runs the re-integration and the whole reverse sweep
+  // (the table follows the accepted steps, so it is uploaded asynchronously rather than cached); when the walk is unavailable the
+  // same rows are replayed as ordinary launches, with bit-identical results.
+  const bool order1 = all_64(f);   // order-1 stage combines are what the adaptive walk takes (other stacks: one launch per layer)
+  ODEHIP_CHECK_HIP(hipMemsetAsync(L.p(ws, L.off_gy), 0, st_b, stream));   // (before the rows: everything recorded runs at finish())
+  rc = odehip_nchw_to_q4(z0_nchw, L.xin(ws, 0, 0), batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
+  int n_out_max = 1;
+  for (int n = 0; n < N; ++n) n_out_max = j_hi[n] - j_lo[n] > n_out_max ? j_hi[n] - j_lo[n] : n_out_max;
+  const int ew_per_seed = (n_out_max + 6 + ODEHIP_MAX_STAGES) / ODEHIP_MAX_STAGES + 1;
+  PersistScope persist;
+  if ((rc = persist.begin(f, f_dgrad, 2 * (6 * N + 1) * NL + (8 * N + 2) * ew_per_seed)) != ODEHIP_OK) return rc;
+  persist.set_volatile_table(true);
+
   float* hidv[ODEHIP_MAX_LAYERS];
   auto run_f = [&](int n, int s, const float* x, const CombineArgs& c) {
     for (int l = 0; l < NH; ++l) hidv[l] = L.hidden(ws, n, s, l);
     return enqueue_f_saving(f, x, batch, hidv, ping, pong, &c, nullptr, nullptr, stream);
   };
-  auto axpy = [&](float* out, std::vector<const float*>& src, std::vector<float>& c, bool zero_if_empty) {
-    bool acc = false;
+  // out = sum_j c[j] * src[j] as elementwise rows of at most ODEHIP_MAX_STAGES sources (later rows accumulate); zero if empty
+  auto axpy = [&](float* out, std::vector<const float*>& src, std::vector<float>& c) -> int {
     size_t o = 0;
-    if (src.empty() && zero_if_empty) {
-      (void)hipMemsetAsync(out, 0, st_b, stream);
-      return;
-    }
-    while (o < src.size()) {
-      MultiAxpy a;
+    bool acc = false;
+    do {
+      ConvArgs a;
       memset(&a, 0, sizeof(a));
-      a.n = (int)(src.size() - o < 8 ? src.size() - o : 8);
-      for (int j = 0; j < a.n; ++j) {
-        a.src[j] = src[o + j];
-        a.c[j] = c[o + j];
+      a.combine = 4;
+      a.qout = L.C / 4;
+      a.batch = batch;
+      a.cmb.order = 1;
+      a.cmb.y = acc ? out : nullptr;
+      a.cmb.out1 = out;
+      const size_t m = src.size() - o < (size_t)ODEHIP_MAX_STAGES ? src.size() - o : (size_t)ODEHIP_MAX_STAGES;
+      a.cmb.n_prev = (int)m;
+      for (size_t j = 0; j < m; ++j) {
+        a.cmb.k_prev[j] = src[o + j];
+        a.cmb.c1[j] = c[o + j];
       }
-      a.accumulate = acc;
-      a.out = out;
-      hipLaunchKernelGGL(multi_axpy_kernel, dim3(1024), dim3(256), 0, stream, a, n4);
+      int r = launch_conv(a, f->ks, stream);
+      if (r != ODEHIP_OK) return r;
+      o += m;
       acc = true;
-      o += a.n;
-    }
+    } while (o < src.size());
+    return ODEHIP_OK;
   };
 
   // ---- 1. re-integrate the accepted steps, keeping activations ------------------------------------------------------------
-  rc = odehip_nchw_to_q4(z0_nchw, L.xin(ws, 0, 0), batch, L.C, stream);
-  if (rc != ODEHIP_OK) return rc;
+  // The stage-2 input of a step, Y_2 = y0 + h*beta21*k1, rides in the epilogue of the evaluation that produces k1: f(z0) for the
+  // first step, the previous step's stage 7 (FSAL) for the others.
   CombineArgs c;
   memset(&c, 0, sizeof(c));
   c.k_scale = 1.0f;
+  c.order = order1;
   c.k_out = k[0];
-  if ((rc = run_f(0, 0, L.xin(ws, 0, 0), c)) != ODEHIP_OK) return rc;  // k1 of the first step
+  c.y = L.xin(ws, 0, 0);
+  c.h_ptr = hdev;
+  c.c1[0] = (float)dp5::kBeta[0][0];
+  c.out1 = L.xin(ws, 0, 1);
+  if ((rc = run_f(0, 0, L.xin(ws, 0, 0), c)) != ODEHIP_OK) return rc;  // k1 of the first step (+ its Y_2)
   for (int n = 0; n < N; ++n) {
     const float* y0 = n == 0 ? L.xin(ws, 0, 0) : L.xin(ws, n - 1, 6);
-    {  // Y_2 = y0 + h*beta21*k1
-      MultiAxpy a;
-      memset(&a, 0, sizeof(a));
-      a.n = 2;
-      a.src[0] = y0; a.c[0] = 1.0f;
-      a.src[1] = k[0]; a.c[1] = (float)dp5::kBeta[0][0] * (float)accepted_host[2 * n + 1];
-      a.out = L.xin(ws, n, 1);
-      hipLaunchKernelGGL(multi_axpy_kernel, dim3(1024), dim3(256), 0, stream, a, n4);
-    }
     for (int s = 2; s <= 7; ++s) {
       memset(&c, 0, sizeof(c));
       c.k_scale = 1.0f;
-      c.y = y0;
-      c.h_ptr = hdev + n;
-      c.n_prev = s - 1;
-      for (int j = 0; j < s - 1; ++j) c.k_prev[j] = k[j];
+      c.order = order1;
       c.k_out = k[s - 1];
       if (s <= 6) {
+        c.y = y0;
+        c.h_ptr = hdev + n;
+        c.n_prev = s - 1;
+        for (int j = 0; j < s - 1; ++j) c.k_prev[j] = k[j];
         for (int j = 0; j < s; ++j) c.c1[j] = (float)dp5::kBeta[s - 1][j];
         c.out1 = L.xin(ws, n, s);  // Y_{s+1}; s = 6: y1
+      } else if (n + 1 < N) {      // k7 = k1 of the next step: its Y_2 = y1 + h_{n+1}*beta21*k7
+        c.y = L.xin(ws, n, 6);
+        c.h_ptr = hdev + n + 1;
+        c.c1[0] = (float)dp5::kBeta[0][0];
+        c.out1 = L.xin(ws, n + 1, 1);
       }
       if ((rc = run_f(n, s - 1, L.xin(ws, n, s - 1), c)) != ODEHIP_OK) return rc;
     }
@@ -237,7 +242,6 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
   float* gy_new = L.p(ws, L.off_gy + L.st);
   float* gk1 = L.p(ws, L.off_gk1);               // gradient w.r.t. k1 of the step after the one being processed (= its k7)
   float* gk1_new = L.p(ws, L.off_gk1 + L.st);
-  ODEHIP_CHECK_HIP(hipMemsetAsync(gy, 0, st_b, stream));
   bool have_gk1 = false;
   std::vector<const float*> src;
   std::vector<float> cf;
@@ -272,7 +276,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
         cf.push_back(1.0f);
       }
       if (s >= 2) {
-        axpy(L.gp(ws, n, s - 1, NH), src, cf, true);
+        if ((rc = axpy(L.gp(ws, n, s - 1, NH), src, cf)) != ODEHIP_OK) return rc;
         BwdArgs w;
         memset(&w, 0, sizeof(w));
         w.n_targets = 1;
@@ -284,9 +288,9 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
         }
         if ((rc = chain(n, s - 1, w)) != ODEHIP_OK) return rc;
       } else if (n > 0) {
-        axpy(gk1_new, src, cf, true);  // k1 of this step is k7 of the previous one
+        if ((rc = axpy(gk1_new, src, cf)) != ODEHIP_OK) return rc;  // k1 of this step is k7 of the previous one
       } else {
-        axpy(L.gp(ws, 0, 0, NH), src, cf, true);  // k1 = f(z0)
+        if ((rc = axpy(L.gp(ws, 0, 0, NH), src, cf)) != ODEHIP_OK) return rc;  // k1 = f(z0)
       }
     }
     // gradient w.r.t. y0 of this step
@@ -300,7 +304,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
       src.push_back(gY[s - 1]);
       cf.push_back(1.0f);
     }
-    axpy(gy_new, src, cf, true);
+    if ((rc = axpy(gy_new, src, cf)) != ODEHIP_OK) return rc;
     float* t = gy; gy = gy_new; gy_new = t;
     t = gk1; gk1 = gk1_new; gk1_new = t;
     have_gk1 = true;
@@ -316,28 +320,41 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
     w.tgt[0].srcB = goq(0);
     w.tgt[0].b_c = 1.0f;
     if ((rc = chain(0, 0, w)) != ODEHIP_OK) return rc;
-    rc = odehip_q4_to_nchw(gy_new, grad_z0_nchw, batch, L.C, stream);
-    if (rc != ODEHIP_OK) return rc;
   }
+  if ((rc = persist.finish(nullptr, nullptr, nullptr, batch, (unsigned*)L.p(ws, L.off_psync), f->ks, stream)) != ODEHIP_OK) return rc;
+  rc = odehip_q4_to_nchw(gy_new, grad_z0_nchw, batch, L.C, stream);
+  if (rc != ODEHIP_OK) return rc;
 
-  // ---- 3. weight / bias gradients: one launch per layer over all stage evaluations ----------------------------------------------
+  // ---- 3. weight / bias gradients: one launch per layer over all stage evaluations; the NL tables travel in ONE staged upload
   const int n_eval = 6 * N + 1;
   WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
   float* slabs = L.p(ws, L.off_slab);
-  std::vector<WgradPair> host(n_eval);
+  std::vector<WgradPair> host((size_t)n_eval * NL);
   for (int l = 0; l < NL; ++l) {
     int e = 0;
     for (int n = 0; n < N; ++n)
       for (int s = (n == 0 ? 0 : 1); s < 7; ++s, ++e) {
-        host[e].g = L.gp(ws, n, s, l);
-        host[e].a = l == 0 ? L.xin(ws, n, s) : L.hidden(ws, n, s, l - 1);
-        host[e].scale = 1.0f;
-        host[e].pad_[0] = host[e].pad_[1] = host[e].pad_[2] = 0.0f;
+        WgradPair& hp = host[(size_t)l * n_eval + e];
+        hp.g = L.gp(ws, n, s, l);
+        hp.a = l == 0 ? L.xin(ws, n, s) : L.hidden(ws, n, s, l - 1);
+        hp.scale = 1.0f;
+        hp.pad_[0] = hp.pad_[1] = hp.pad_[2] = 0.0f;
       }
-    ODEHIP_CHECK_HIP(hipMemcpyAsync(table, host.data(), (size_t)n_eval * sizeof(WgradPair), hipMemcpyHostToDevice, stream));
-    ODEHIP_CHECK_HIP(hipStreamSynchronize(stream));
-    rc = launch_wgrad(table, n_eval, batch, 4, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream, f->w_bf16[l] != nullptr);
+  }
+  if ((rc = staged_upload(table, host.data(), host.size() * sizeof(WgradPair), stream)) != ODEHIP_OK) return rc;
+  for (int l = 0; l < NL; ++l) {
+    rc = launch_wgrad(table + (size_t)l * n_eval, n_eval, batch, 4, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream,
+                      f->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
-  return ODEHIP_OK;
+  // a give-up of the walk must not hand plausible numbers to the caller: NaN-fill what this call returns
+  float* regions[2 * ODEHIP_MAX_LAYERS + 1];
+  size_t floats[2 * ODEHIP_MAX_LAYERS + 1];
+  int nr = 0;
+  regions[nr] = grad_z0_nchw; floats[nr++] = st_b / 4;
+  for (int l = 0; l < NL; ++l) {
+    regions[nr] = grad_w[l]; floats[nr++] = (size_t)f->channels[l + 1] * f->channels[l] * 9;
+    regions[nr] = grad_b[l]; floats[nr++] = (size_t)f->channels[l + 1];
+  }
+  return persist.guard(regions, floats, nr, stream);
 }

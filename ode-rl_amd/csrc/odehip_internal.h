@@ -54,7 +54,18 @@ struct CombineArgs {
   float* err_partials;
   float ce[ODEHIP_MAX_STAGES + 1];
   float rtol, atol;
+  // Summation order of the stage combine.  0 (fixed-grid drivers): s = c[n]*k_cur, then += c[j]*k_prev[j].  1 (the adaptive
+  // solver's drivers): explicit fmas over k_prev[0..n-1] FIRST, k_cur last, out = fma(s, h, y) -- the part that does not depend
+  // on the conv output can then be formed while the matrix cores still work on the layer (the persistent walk's adaptive kernel
+  // holds three partial sums instead of up to six earlier stages), and every kernel that evaluates the expression rounds it the
+  // same way (no contraction left to the compiler), so the walk stays bit-identical to one launch per layer.
+  int order;
 };
+// ---- elementwise rows (ConvArgs::combine == 4): no convolution.  Uses the CombineArgs fields:
+//   out1 = (y ? y : 0) + sum_{j < n_prev} (c1[j] * hs) * k_prev[j]        hs = *h_ptr (1 if null)
+//   out2 = (y ? y : 0) + sum_{j < n_prev} (c2[j] * hs) * k_prev[j]        (only if out2 != null)
+// evaluated as explicit fmas in j order.  In a persistent walk a lane only touches the elements the conv epilogues give it
+// (channel quad Q of its 2x2 output tile), i.e. data it wrote itself: no wait, no barrier; the row then announces itself like a layer.
 
 // ---- epilogues of the input-gradient (dgrad) convolutions of the backward sweep
 //   combine == 2: dst = scale * acc * (mask_src > 0)            (ReLU backward fused; scale = sc_c + sc_h*h)
@@ -87,7 +98,7 @@ struct ConvArgs {
   int qout;    // output quads (cout / 4)
   int batch;
   int relu;
-  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue; 2/3: BwdArgs epilogues
+  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue; 2/3: BwdArgs epilogues; 4: elementwise row (no conv; see above)
   int debug;   // diagnostic ablation bits (tools/conv_microbench.py): 1 skip DMA, 2 skip MFMA, 4 skip epilogue
   int h_by_value;  // persistent tables of fixed-grid drivers: cmb.atol holds the step size itself (read instead of *h_ptr)
   const int* skip;          // if non-null and *skip != 0 the kernel does nothing (adaptive solver already done)
@@ -107,7 +118,10 @@ extern thread_local ConvRecorder* g_conv_recorder;
 int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned epoch,
                               unsigned* host_err_dev, int grid, hipStream_t stream);
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                        float* out_nchw, int grid, hipStream_t stream, bool wide = false);  // wide: the table has 128-channel layers
+                        float* out_nchw, int grid, hipStream_t stream, bool wide = false,  // wide: the table has 128-channel layers
+                        bool adaptive = false, const int* n_layers_ptr = nullptr);          // adaptive: wino_persist_d_kernel (order-1
+                                                                                            // combines, elementwise rows, h on the device)
+int launch_ew_row(const ConvArgs& a, hipStream_t stream);   // an elementwise row (combine == 4) as an ordinary launch
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_wino5(const ConvArgs& a, hipStream_t stream);  // 5x5 layers with a.w_wino (conv_wino5.hip); 1 = no such form, run the direct kernel
 int launch_bf16(const ConvArgs& a, hipStream_t stream);
@@ -135,6 +149,13 @@ extern unsigned long long* g_debug_buf;
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
 int check_stack(const odehip_convstack* f);
+// every layer 64 -> 64, 3x3: the stacks the adaptive persistent walk takes (their adaptive drivers write order-1 stage combines)
+inline bool all_64(const odehip_convstack* f) {
+  if (f->ks != 3) return false;
+  for (int l = 0; l <= f->n_convs; ++l)
+    if (f->channels[l] != 64) return false;
+  return true;
+}
 // prologue of a fixed-grid trajectory in one launch: NCHW -> Q4 + verbatim copy (solution[0] = y0), n_h <= 64 step sizes into hdev,
 // n_zero words zeroed (the persistent launch's flag area; may be null)
 int traj_prologue(const float* src, float* dst_q4, float* copy_nchw, int batch, int channels, const float* h_host, int n_h, float* hdev,

@@ -22,6 +22,10 @@ class PersistScope {
   // flags); such a scope stays inactive inside an outer scope, whose recorder then simply sees the layers
   int begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers, bool small = false);
   bool active() const { return active_; }
+  // volatile_table: the recorded table differs from call to call (buffers / coefficients that follow the accepted steps of an
+  // adaptive solve): it is uploaded asynchronously through a ring instead of entering the content cache (whose misses cost a
+  // stream synchronisation).  Call between begin() and finish().
+  void set_volatile_table(bool v) { volatile_ = v; }
   // hbuf / hdev: host copy and device array of the step sizes (fixed grids: the table gets h by value), or null / null when the
   // step size only exists on the device (dopri5); out_nchw may be null; sync: persist_sync_bytes(batch) of workspace
   // sync_is_zero: the caller has already zeroed the flag area on this stream (traj_prologue)
@@ -39,6 +43,8 @@ class PersistScope {
   ConvRecorder rec_ = {nullptr, 0, 0};
   bool active_ = false;
   bool small_ = false;
+  bool adaptive_ = false;
+  bool volatile_ = false;
   bool launched_ = false;
   const unsigned* abort_word_ = nullptr;
 };
@@ -47,6 +53,9 @@ class PersistScope {
 // (odehip_set_persistent_trajectory / ODEHIP_PERSISTENT=0) and are counted by odehip_persistent_trajectory_launches().
 bool persist_switch_on();
 void persist_count_launch();
+
+// asynchronous host -> device copy through a ring of pinned staging slots (no stream synchronisation, no pageable memory)
+int staged_upload(void* dst_dev, const void* src, size_t bytes, hipStream_t stream);
 
 // host-side look at the sticky error word of the persistent launches (0 = none); clear != 0 resets it and disables the path
 unsigned persist_error(bool clear);

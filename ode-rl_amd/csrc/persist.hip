@@ -24,6 +24,19 @@ struct PersistState {
   unsigned* host_err_dev = nullptr;
   int enabled = -1;                  // -1 unknown, 0 off (env, device, or a failed launch), 1 on
   long long launches = 0;
+  // Tables that differ from call to call (the backward passes of the adaptive solver: buffers, step sizes and dense-output weights
+  // follow the accepted steps) bypass the content cache: a ring of device slots filled through staged_upload() -- an
+  // ASYNCHRONOUS transfer on the caller's stream, no stream synchronisation.  A slot is reused kVolSlots uploads later;
+  // the event recorded behind the launch that read it says when that is safe (long past by then: the wait is a formality).
+  static constexpr int kVolSlots = 4;
+  struct VolSlot {
+    ConvArgs* dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+  } vol[kVolSlots];
+  int vol_next = 0;
+  int vol_last = -1;   // slot of the upload that has not been followed by its launch yet
   // small launches: flag area that is never zeroed between launches (words are tagged with the launch's epoch)
   unsigned* small_flags = nullptr;
   int small_batch_cap = 0;
@@ -49,9 +62,12 @@ static bool persist_available() {
 
 // 0: not for a persistent walk; 1: a 64 -> 64 layer (the headline kernel); 2: a layer with a 128-channel side (128 -> 64 or
 // 64 -> 128: the wide walk)
+// 3: a row only the ADAPTIVE walk takes (wino_persist_d_kernel): an elementwise row, or a 64 -> 64 layer whose stage combine is
+//    written in order 1 (the adaptive solver's drivers)
 static int persist_layer_kind(const ConvArgs& a) {
+  if (a.combine == 4) return a.qout == 16 && !a.src2 ? 3 : 0;
   if (!a.w_wino || a.w_bf16 || a.src2 || a.q1 != a.qin || a.combine < 0 || a.combine > 3) return 0;
-  if (a.qin == 16 && a.qout == 16) return 1;
+  if (a.qin == 16 && a.qout == 16) return (a.combine == 1 && a.cmb.order == 1) ? 3 : 1;
   if ((a.qin == 32 && a.qout == 16) || (a.qin == 16 && a.qout == 32)) return 2;
   return 0;
 }
@@ -83,6 +99,76 @@ static const ConvArgs* persist_table(const ConvArgs* items, int n, hipStream_t s
   }
   lru->stamp = ++P.clock;
   return lru->dev;
+}
+
+// Host -> device copy WITHOUT a stream synchronisation and without pageable memory on the stream: the bytes are copied into a
+// pinned staging slot (a ring; a slot is free again once the event recorded behind ITS copy has passed) and transferred
+// asynchronously on the caller's stream.
+struct StageSlot {
+  char* host = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+static std::mutex g_stage_mu;
+static StageSlot g_stage[8];
+static int g_stage_next = 0;
+int staged_upload(void* dst_dev, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return ODEHIP_OK;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  StageSlot& v = g_stage[g_stage_next];
+  g_stage_next = (g_stage_next + 1) % 8;
+  if (v.pending) {
+    ODEHIP_CHECK_HIP(hipEventSynchronize(v.ev));
+    v.pending = false;
+  }
+  if (!v.ev) ODEHIP_CHECK_HIP(hipEventCreateWithFlags(&v.ev, hipEventDisableTiming));
+  if (v.cap < bytes) {
+    if (v.host) (void)hipHostFree(v.host);
+    v.host = nullptr;
+    v.cap = 0;
+    const size_t cap = (bytes + 65535) / 65536 * 65536;
+    ODEHIP_CHECK_HIP(hipHostMalloc((void**)&v.host, cap, hipHostMallocDefault));
+    v.cap = cap;
+  }
+  memcpy(v.host, src, bytes);
+  ODEHIP_CHECK_HIP(hipMemcpyAsync(dst_dev, v.host, bytes, hipMemcpyHostToDevice, stream));
+  ODEHIP_CHECK_HIP(hipEventRecord(v.ev, stream));
+  v.pending = true;
+  return ODEHIP_OK;
+}
+
+// device copy of a call-specific table: asynchronous upload into a ring of device slots (see PersistState::VolSlot); null on failure
+static const ConvArgs* persist_table_async(const ConvArgs* items, int n, hipStream_t stream) {
+  PersistState& P = g_persist;
+  const size_t bytes = (size_t)n * sizeof(ConvArgs);
+  PersistState::VolSlot& v = P.vol[P.vol_next];
+  if (v.pending) {
+    if (hipEventSynchronize(v.ev) != hipSuccess) return nullptr;
+    v.pending = false;
+  }
+  if (!v.ev && hipEventCreateWithFlags(&v.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (v.cap < bytes) {
+    if (v.dev) (void)hipFree(v.dev);
+    v.dev = nullptr;
+    v.cap = 0;
+    const size_t cap = (bytes + 65535) / 65536 * 65536;
+    if (hipMalloc((void**)&v.dev, cap) != hipSuccess) return nullptr;
+    v.cap = cap;
+  }
+  if (staged_upload(v.dev, items, bytes, stream) != ODEHIP_OK) return nullptr;
+  P.vol_last = P.vol_next;
+  P.vol_next = (P.vol_next + 1) % PersistState::kVolSlots;
+  return v.dev;
+}
+// behind the launch (or the replay) that read the table of the last persist_table_async()
+static void persist_table_async_done(hipStream_t stream) {
+  PersistState& P = g_persist;
+  if (P.vol_last < 0) return;
+  PersistState::VolSlot& v = P.vol[P.vol_last];
+  P.vol_last = -1;
+  if (hipEventRecord(v.ev, stream) == hipSuccess) v.pending = true;
+  else (void)hipStreamSynchronize(stream);
 }
 
 constexpr int kGuardRegions = 24;
@@ -197,13 +283,15 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;
     if (!active_) return ODEHIP_OK;
     active_ = false;
-    bool all_ok = rec_.count > 0, wide = false;
+    bool all_ok = rec_.count > 0, wide = false, adaptive = adaptive_;
     for (int i = 0; i < rec_.count && all_ok; ++i) {
       const int kind = persist_layer_kind(rec_.items[i]);
       all_ok = kind != 0;
       wide = wide || kind == 2;
+      adaptive = adaptive || kind == 3;
     }
-    if (wide && small_) all_ok = false;
+    if (wide && (small_ || adaptive)) all_ok = false;   // (order-1 rows of a 128-channel-ended stack: one launch per layer)
+    if (adaptive && small_) all_ok = false;
     if (small_ && all_ok && rec_.count <= 5) {
       PersistState& P = g_persist;
       bool ready = true;
@@ -258,13 +346,14 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
           a.cmb.out2_nchw = nullptr;
         }
       }
-      table = persist_table(rec_.items, rec_.count, stream);
+      table = volatile_ ? persist_table_async(rec_.items, rec_.count, stream) : persist_table(rec_.items, rec_.count, stream);
     }
     int rc;
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
-                               kPersistGrid, stream, wide);
+                               kPersistGrid, stream, wide, adaptive, nullptr);
+      if (volatile_) persist_table_async_done(stream);
       if (rc == ODEHIP_OK) {
         ++g_persist.launches;
         launched_ = true;
