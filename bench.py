@@ -343,7 +343,7 @@ def main():
             with torch.no_grad():
                 return solver(z0, t)
         zz = z0.detach().requires_grad_(True)
-        f.zero_grad(set_to_none=False)
+        f.zero_grad()   # torch 2 default (set_to_none=True), what the reference's `optimizer.zero_grad()` (train_test.py:176) does today
         if a.adjoint:
             o = ode_rl_amd.odeint_adjoint(f, zz, t, rtol=solver.odeint_rtol, atol=solver.odeint_atol, method=a.method,
                                           adjoint_options={"norm": a.adjoint_norm} if a.method == "dopri5" else None)
@@ -420,7 +420,7 @@ def main():
 
         def train_step():
             zz = z0.detach().requires_grad_(True)
-            f.zero_grad(set_to_none=False)
+            f.zero_grad()   # torch 2 default (set_to_none=True), what the reference's `optimizer.zero_grad()` (train_test.py:176) does today
             o = solver(zz, t)
             o.backward(gout2)
             if dist is not None:

@@ -18,7 +18,10 @@
  *       * odehip_odeint_dopri5 returns after the device-side controller has reported completion: it polls a pinned
  *         64 KiB host mailbox that the library allocates on first use (hipHostMalloc);
  *       * odehip_odeint_adjoint_dopri5_backward reads one 8-byte verdict per attempted step from pinned host memory it
- *         allocates on first use, and odehip_odeint_dopri5_backward synchronises once per layer for its wgrad table;
+ *         allocates on first use;
+ *       * tables that follow the accepted steps of an adaptive solve (odehip_odeint_dopri5_backward[_saved]: its layer table and its
+ *         weight-gradient tables) travel through a library-owned ring of pinned staging buffers and device slots with asynchronous
+ *         copies on the caller's stream -- no stream synchronisation (hipHostMalloc / hipMalloc when a slot has to grow);
  *       * the "small" persistent launches (ODEHIP_PERSISTENT_SMALL=1 only) own a flag area in device memory;
  *       * odehip_odeint_fixed_backward with saved_format 1 (bf16 whole-trajectory path) runs its weight-gradient launches on a
  *         library-owned side stream, ordered against the caller's stream by events in both directions (the caller's stream
@@ -44,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 6 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 7 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -328,13 +331,31 @@ int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const 
  * modules/DiffEqSolver.py:9, train_test.py:204): the gradient of the arithmetic of the accepted steps (what autograd
  * through torchdiffeq differentiates; step sizes are constants, as under torchdiffeq's no_grad step-size update).
  * Re-integrates the `n_steps` accepted steps of the forward call from z0 keeping activations (n_steps * ~3.5 state-sized
- * tensors per conv layer), walks them backwards, one weight-gradient launch per layer at the end.  Enqueue-only apart
- * from one synchronisation per layer for the wgrad table.  3x3 dynamics, channels % 64 == 0, increasing t. */
+ * tensors per conv layer), walks them backwards, one weight-gradient launch per layer at the end.  Enqueue-only.  For 64-channel
+ * fp32 stacks the re-integration and the whole reverse sweep are ONE launch of the adaptive persistent walk (DESIGN.md section
+ * 4.4a).  3x3 dynamics, channels % 64 == 0, increasing t. */
 size_t odehip_dopri5_backward_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int n_steps);
 int odehip_odeint_dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host, int n_times,
                                   int batch, const double* accepted_host, int n_steps, const float* z0_nchw,
                                   const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w, float* const* grad_b,
                                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same pair WITHOUT the re-integration: the forward of a training step keeps the stage inputs and hidden activations of every
+ * accepted step (an attempt writes them into a slot chosen on the device; a rejected attempt's slot is reused), the backward walks
+ * them in reverse.  odehip_odeint_dopri5_saving = odehip_odeint_dopri5 (same arguments; no `negate`) + max_accept slots of
+ * workspace (odehip_dopri5_saving_workspace_bytes; ~140 MB per slot at B=64) + *saved_out: 1 if the activations are in the
+ * workspace, 0 if nothing was saved (the stack is not a 64-channel fp32 stack, the persistent walk is unavailable, exact-global
+ * step control is on, or more than max_accept steps were accepted) -- the caller then uses odehip_odeint_dopri5_backward.
+ * odehip_odeint_dopri5_backward_saved takes that workspace (untouched since the forward) with the forward's accepted-step log. */
+size_t odehip_dopri5_saving_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int max_accept);
+int odehip_odeint_dopri5_saving(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
+                                float rtol, float atol, double first_step, int max_steps, float* out_nchw, int* stats_host,
+                                double* accepted_host, int accepted_cap, int max_accept, int* saved_out, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int odehip_odeint_dopri5_backward_saved(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host, int n_times,
+                                        int batch, const double* accepted_host, int n_steps, const float* grad_out_nchw,
+                                        float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, int max_accept,
+                                        void* saved_workspace, size_t saved_workspace_bytes, void* stream);
 
 /* ---- optimizer step of the training loop (train_test.py:24,205: optim.Adam(model.parameters(), lr)) ------------------------ */
 

@@ -45,8 +45,10 @@ class _Dopri5Odeint(torch.autograd.Function):
     def forward(ctx, y0, t_host, cfg, stack, *params):
         ctx.mode = hip_ops.current_compute_dtype()
         y0d = y0.detach()
-        out, stats = hip_ops.odeint_dopri5(stack, y0d, t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
-                                           max_steps=cfg["max_num_steps"])
+        # the forward keeps the activations of the accepted steps when it can (64-channel fp32 stacks on the adaptive walk): the
+        # backward is then the reverse sweep alone; otherwise ctx.saved is None and the backward re-integrates the logged steps
+        out, stats, ctx.saved = hip_ops.odeint_dopri5_saving(stack, y0d, t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
+                                                             max_steps=cfg["max_num_steps"])
         from .odeint import last_stats
         last_stats.clear()
         last_stats.update(stats)
@@ -65,7 +67,11 @@ class _Dopri5Odeint(torch.autograd.Function):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
         (y0,) = ctx.saved_tensors
-        gz0, gws, gbs = hip_ops.odeint_dopri5_backward(ctx.stack, ctx.t_host, ctx.accepted, y0, grad_out)
+        if ctx.saved is not None and len(ctx.accepted) >= 1:
+            gz0, gws, gbs = hip_ops.odeint_dopri5_backward_saved(ctx.stack, ctx.t_host, ctx.accepted, grad_out, ctx.saved)
+            ctx.saved = None
+        else:
+            gz0, gws, gbs = hip_ops.odeint_dopri5_backward(ctx.stack, ctx.t_host, ctx.accepted, y0, grad_out)
         grads = []
         for gw, gb in zip(gws, gbs):
             grads += [gw, gb]

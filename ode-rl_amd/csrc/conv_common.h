@@ -84,7 +84,7 @@ __device__ __forceinline__ void ew_quad(const CombineArgs& m, size_t off, float 
   f32x4 s2 = s1;
   for (int j = 0; j < m.n_prev; ++j) {
     const f32x4 kp = *(const f32x4*)(m.k_prev[j] + off);
-    s1 = fma4(kp, m.c1[j] * hs, s1);
+    s1 = fma4(kp, (m.c_dev ? m.c_dev[j] : m.c1[j]) * hs, s1);
     if (m.out2) s2 = fma4(kp, m.c2[j] * hs, s2);
   }
   if (m.out1) *(f32x4*)(m.out1 + off) = s1;

@@ -61,7 +61,22 @@ struct PersistHook {
   bool announce;       // false: the first of a workgroup's two passes over a 128-channel layer -- its flags are stored after the second
   bool split_wait;     // the input chunks 0/1 and 2/3 come from the two co tiles of a 64 -> 64 layer: wait for them separately
   int sleep6;          // solo: s_sleep(6) periods (0.18 us each) in front of the first poll
+  const unsigned long long* reloc;  // adaptive walk: base addresses of the relocation classes (rel() below), or null
 };
+
+// Relocatable pointers of the adaptive walk's tables.  A driver whose buffers are chosen ON THE DEVICE (the slot an adaptive
+// solver's accepted step keeps, the state pointers that swap with FSAL) writes such a pointer as  class << 56 | byte offset  and a
+// device-side controller keeps reloc[class] = the base address current for the next launch; the walk resolves the field when it
+// reads the row (scalar arithmetic on uniform values).  Class 0 = an ordinary pointer.  User-space addresses have their top 16
+// bits clear, so the tag cannot collide with one.
+template <typename T>
+__device__ __forceinline__ T* rel(const unsigned long long* reloc, T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned cls = (unsigned)(v >> 56);
+  if (cls == 0) return p;
+  typedef const __attribute__((address_space(4))) unsigned long long ConstU;
+  return (T*)((v & 0x00ffffffffffffffull) + *((ConstU*)reloc + cls));
+}
 __device__ __forceinline__ void pstamp(const PersistHook& hk, int i, int lane) {
   if (hk.stamps && lane == 0) hk.stamps[i] = __builtin_amdgcn_s_memrealtime();
 }
@@ -294,8 +309,10 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
   bool d_has_y = false, d_err = false, d_f[4] = {false, false, false, false};
   if constexpr (ADAPT) {
     typedef const __attribute__((address_space(4))) float ConstF;
+    const unsigned long long* const rl = hk.reloc;   // relocatable pointers (rel()): every pointer of the reduced paths below is
+                                                     // resolved here; rows that fall to the shared epilogue (kind 5) must not carry any
     e_relu = a.relu;
-    e_dst = a.dst;
+    e_dst = rel(rl, a.dst);
     d_kind = a.combine == 0 ? 0 : 5;
     if (a.combine == 2) {
       const BwdArgs& w = a.bwd;
@@ -303,10 +320,11 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       d_ks = w.sc_c + w.sc_h * hb;
       d_has_y = w.mask_src != nullptr;
       d_kind = 2;
+      const float* const mask = rel(rl, w.mask_src);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
-        if (d_has_y) d_y[q] = *(const f32x4*)(w.mask_src + off);
+        if (d_has_y) d_y[q] = *(const f32x4*)(mask + off);
       }
     } else if (a.combine == 3 && a.bwd.n_targets <= 2 && !a.bwd.h_ptr) {
       const BwdArgs& w = a.bwd;
@@ -315,18 +333,20 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       for (int t = 0; t < 2; ++t) {
         if (t < w.n_targets) {
           const BwdTarget& T = w.tgt[t];
-          d_o[t] = T.out;
+          d_o[t] = rel(rl, T.out);
           d_t[3 * t] = T.g_c; d_t[3 * t + 1] = T.a_c; d_t[3 * t + 2] = T.b_c;
           d_f[2 * t] = T.srcA != nullptr; d_f[2 * t + 1] = T.srcB != nullptr;
+          const float* const sA = rel(rl, T.srcA);
+          const float* const sB = rel(rl, T.srcB);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
             if (t == 0) {
-              if (d_f[0]) d_y[q] = *(const f32x4*)(T.srcA + off);
-              if (d_f[1]) d_y1[q] = *(const f32x4*)(T.srcB + off);
+              if (d_f[0]) d_y[q] = *(const f32x4*)(sA + off);
+              if (d_f[1]) d_y1[q] = *(const f32x4*)(sB + off);
             } else {
-              if (d_f[2]) d_sa[q] = *(const f32x4*)(T.srcA + off);
-              if (d_f[3]) d_sb[q] = *(const f32x4*)(T.srcB + off);
+              if (d_f[2]) d_sa[q] = *(const f32x4*)(sA + off);
+              if (d_f[3]) d_sb[q] = *(const f32x4*)(sB + off);
             }
           }
         }
@@ -342,21 +362,23 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
       d_cA = m.c1[np];
       d_cB = d_err ? m.ce[np] : m.c2[np];
       d_rtol = m.rtol; d_atol = m.atol;
-      d_o[0] = m.k_out; d_o[1] = m.out1; d_o[2] = m.out2;
+      d_o[0] = rel(rl, m.k_out); d_o[1] = rel(rl, m.out1); d_o[2] = rel(rl, m.out2);
       d_o[3] = a.dbg ? hk.nchw_base + ((size_t)a.dbg - 1) : m.out2_nchw;
       const bool needB = d_err || d_o[2] || d_o[3];
+      const float* const yp = rel(rl, m.y);
+      const float* const y1p = rel(rl, m.err_y1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         d_sa[q] = d_sb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (d_has_y) {
           const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
-          d_y[q] = *(const f32x4*)(m.y + off);
-          if (d_err) d_y1[q] = *(const f32x4*)(m.err_y1 + off);
+          d_y[q] = *(const f32x4*)(yp + off);
+          if (d_err) d_y1[q] = *(const f32x4*)(y1p + off);
         }
       }
       if (d_has_y) {
         for (int j = 0; j < np; ++j) {   // the sums over the earlier stages, in the order of combine1_prev (conv_common.h)
-          const float* kp = m.k_prev[j];
+          const float* kp = rel(rl, m.k_prev[j]);
           const float cA = m.c1[j], cB = d_err ? m.ce[j] : m.c2[j];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -612,7 +634,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true, 0};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true, 0, nullptr};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -640,8 +662,9 @@ struct PersistArgs {
   int sleep6_combine;     // added in front of a layer whose input comes out of a stage-combine epilogue
   unsigned epoch;         // 0: the flag area was zeroed for this launch; else the flags persist across launches and every word is
                           // tagged with the epoch of the launch that wrote it (flag = epoch << 10 | layers done; xcc = epoch << 4 | id)
-  const int* n_layers_ptr;  // adaptive walk only: if non-null the number of rows to walk is read from the device (a table that a
-                            // device-side controller wrote for this launch); n_layers is then the capacity
+  const int* n_layers_ptr;  // adaptive walk only: if non-null, {first row, number of rows} of this launch's walk are read from the
+                            // device (a device-side controller picks the section of the table); n_layers is then the table's size
+  const unsigned long long* reloc;  // adaptive walk only: relocation bases (rel()), or null
 };
 
 // An elementwise row of the adaptive walk (ConvArgs::combine == 4, odehip_internal.h).  Only the consumer waves work, each lane on
@@ -654,16 +677,42 @@ __device__ __forceinline__ void ew_row(const ConvArgs& a, int b, int ct, int rh,
   if (wave >= 4) return;
   typedef const __attribute__((address_space(4))) float ConstF;
   const CombineArgs& m = a.cmb;
+  const unsigned long long* const rl = hk.reloc;
   const float hs = m.h_ptr ? *(ConstF*)m.h_ptr : 1.0f;
   const int ch = wave >> 1, thh = wave & 1, i16 = lane & 15, kq = lane >> 4;
   const int Q = ct * 8 + ch * 4 + kq, tile = thh * 16 + i16, oty = tile >> 3, otx = tile & 7, r0 = rh * 8;
+  const float* const yp = rel(rl, m.y);
+  float* const o1 = rel(rl, m.out1);
+  float* const o2 = rel(rl, m.out2);
+  f32x4 s1[4], s2[4];
+  size_t off[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) ew_quad(m, (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4, hs);
+  for (int q = 0; q < 4; ++q) {
+    off[q] = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+    s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (yp) s1[q] = *(const f32x4*)(yp + off[q]);
+    s2[q] = s1[q];
+  }
+  for (int j = 0; j < m.n_prev; ++j) {   // ew_quad's fma sequence (conv_common.h), four quads at a time
+    const float* const kp = rel(rl, m.k_prev[j]);
+    const float c1 = (m.c_dev ? ((ConstF*)m.c_dev)[j] : m.c1[j]) * hs;
+    const float c2 = m.c2[j] * hs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 kv = *(const f32x4*)(kp + off[q]);
+      s1[q] = fma4(kv, c1, s1[q]);
+      if (o2) s2[q] = fma4(kv, c2, s2[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (o1) *(f32x4*)(o1 + off[q]) = s1[q];
+    if (o2) *(f32x4*)(o2 + off[q]) = s2[q];
+  }
   wait_vmcnt<0>();
   if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   if (lane == 0) __hip_atomic_store(hk.done + hk.word0 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
 
 template <bool ADAPT>
 __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvArgs* table) {
@@ -698,9 +747,11 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
   int n_layers = pa.n_layers;
   if constexpr (ADAPT) {
     typedef const __attribute__((address_space(4))) int ConstI;
-    if (pa.n_layers_ptr) {
-      const int n_dev = *(ConstI*)pa.n_layers_ptr;
-      n_layers = n_dev < n_layers ? n_dev : n_layers;
+    if (pa.n_layers_ptr) {   // {row0, rows}: walk table[row0 .. row0 + rows)
+      const int row0 = ((ConstI*)pa.n_layers_ptr)[0], n_dev = ((ConstI*)pa.n_layers_ptr)[1];
+      if (row0 < 0 || n_dev <= 0 || row0 + n_dev > n_layers) return;   // (uniform) nothing to do / a controller that lost its way
+      table += row0;
+      n_layers = n_dev;
     }
   }
   // A group walks TWO samples at a time, layer by layer in turn (when the batch gives it more than one): the hand-off latency of
@@ -733,10 +784,11 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
-                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0)};
+                                pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0),
+                                ADAPT ? pa.reloc : nullptr};
         if constexpr (ADAPT) {
           if (a.combine == 4) ew_row<16>(a, bs, ct, rh, hk);
-          else wino_layer<4, false, true, 16, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
+          else wino_layer<4, false, true, 16, true>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
         } else {
           wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
         }
@@ -807,7 +859,7 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                           pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false,
-                          pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0)};
+                          pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0), nullptr};
         if (qout == 16) {
           if (qin == 16) wino_layer<4, false, true, 16>(src, u, 16, a, bs, ct, rh, smem, hk);
           else           wino_layer<8, false, true, 16>(src, u, 32, a, bs, ct, rh, smem, hk);
@@ -866,7 +918,8 @@ static int launch_wino_n(const ConvArgs& a, hipStream_t stream) {
 }
 
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                        float* out_nchw, int grid, hipStream_t stream, bool wide, bool adaptive, const int* n_layers_ptr) {
+                        float* out_nchw, int grid, hipStream_t stream, bool wide, bool adaptive, const int* n_layers_ptr,
+                        const unsigned long long* reloc) {
   static bool attr_set = false;
   ODEHIP_REQUIRE(!(wide && adaptive) && (adaptive || !n_layers_ptr), "wino_persist: no adaptive walk for 128-channel-ended stacks");
   if (!attr_set) {
@@ -891,6 +944,7 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   pa.sleep6_combine = sleep6c;
   pa.epoch = 0;  // the caller zeroed the flag area
   pa.n_layers_ptr = n_layers_ptr;
+  pa.reloc = reloc;
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
   if (wide)          hipLaunchKernelGGL(wino_persist_v_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
@@ -916,6 +970,7 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
   sa.pa.table = nullptr; sa.pa.n_layers = n_layers; sa.pa.batch = batch; sa.pa.done = done; sa.pa.xcc_of = xcc_of;
   sa.pa.host_err = host_err_dev; sa.pa.out_nchw = nullptr; sa.pa.stamps = nullptr; sa.pa.sleep6 = 5; sa.pa.sleep6_combine = 4; sa.pa.epoch = epoch;
   sa.pa.n_layers_ptr = nullptr;
+  sa.pa.reloc = nullptr;
   for (int i = 0; i < n_layers; ++i) sa.layers[i] = items[i];
   hipLaunchKernelGGL(wino_persist_small_kernel, dim3(grid), dim3(512), kWinoLds, stream, sa);
   ODEHIP_CHECK_HIP(hipGetLastError());

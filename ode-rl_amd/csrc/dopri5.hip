@@ -17,6 +17,7 @@
 
 #include "odehip_internal.h"
 #include "persist.h"
+#include "dopri5_layout.h"
 
 namespace odehip {
 
@@ -38,13 +39,22 @@ struct DopriState {
   int n_times, n_partials;
   long long n_elems;
   int max_steps;
+  // SAVING mode (the forward of a training step keeps the stage inputs and hidden activations of every ACCEPTED step for the
+  // backward pass: no re-integration).  An attempt writes them into slot `slot_next` of the backward workspace through
+  // relocatable pointers (class 1, conv_wino.hip rel()); a rejected attempt's slot is simply reused, an accepted one moves on.
+  int save_max;        // slots available (0: not saving)
+  int slot_used;       // slot of the attempt that was just judged
+  int slot_next;       // slot of the next attempt
+  int save_ok;         // cleared when more steps were accepted than there are slots (the caller then re-integrates)
+  unsigned long long slot_base, slot_bytes;
+  unsigned long long* reloc;   // [16] relocation bases read by the walk; entry 1 = address of slot_next
 };
 
 constexpr int kMailboxBytes = 65536;
 constexpr int kLogCap = (kMailboxBytes - 64) / 16;
 struct Mailbox {  // pinned host memory, written by the controller with system-scope stores
-  volatile int steps_done, done, status, n_accept, n_reject, nfe;
-  int pad_[10];
+  volatile int steps_done, done, status, n_accept, n_reject, nfe, save_ok;
+  int pad_[9];
   volatile double log[kLogCap][2];  // (t0, dt) of every accepted step, in order (what a backward pass re-integrates)
 };
 
@@ -206,6 +216,19 @@ __global__ __launch_bounds__(256) void controller_kernel(DopriState* st, const f
   }
   if (status) st->status = status;
   st->done = done || status != 0;
+  if (st->save_max > 0) {
+    st->slot_used = st->slot_next;
+    if (accept) {
+      int nx = st->n_accept;
+      if (nx >= st->save_max) {   // out of slots: keep going (the last slot is overwritten), the caller falls back to re-integration
+        if (!st->done) st->save_ok = 0;
+        nx = st->save_max - 1;
+      }
+      st->slot_next = nx;
+    }
+    st->reloc[1] = st->slot_base + (unsigned long long)st->slot_next * st->slot_bytes;
+  }
+  mb->save_ok = st->save_ok;
   mb->n_accept = st->n_accept;
   mb->n_reject = st->n_reject;
   mb->nfe = st->nfe;
@@ -227,12 +250,17 @@ struct FinishArgs {
   float* out_nchw;   // (T,B,C,16,16)
   int channels;
   long long state_floats;
+  long long off_y1, off_x2;   // saving mode: byte offsets of y1 (stage input 6) and of the stage-2 input inside a slot
 };
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a, long long n4, float cm0, float cm2, float cm3, float cm4,
                                                      float cm5, float cm6) {
   const DopriState* st = a.st;
   const int accept = st->accept, j_lo = st->j_lo, j_hi = st->j_hi;
   if (st->done && !(accept && j_hi > j_lo)) return;  // nothing left to write
+  if (st->save_max > 0) {   // y1 of the attempt just judged lies in ITS slot; the next attempt's stage-2 input goes to the next slot
+    a.y1 = (const float*)(st->slot_base + (unsigned long long)st->slot_used * st->slot_bytes + (unsigned long long)a.off_y1);
+    a.x2 = (float*)(st->slot_base + (unsigned long long)st->slot_next * st->slot_bytes + (unsigned long long)a.off_x2);
+  }
   const float hu = st->h_used, hn = st->h;
   const double t0 = st->t0, t1 = st->t1;
   const bool done = st->done;
@@ -292,9 +320,16 @@ __global__ void arm_first_step_kernel(DopriState* st, const double* t_out, doubl
   st->done = st->n_times <= 1;
 }
 __global__ void init_state_kernel(DopriState* st, float rtol, float atol, int n_times, int n_partials, long long n_elems,
-                                  int max_steps) {
+                                  int max_steps, int save_max, unsigned long long slot_base, unsigned long long slot_bytes,
+                                  unsigned long long* reloc) {
   DopriState z;
   memset(&z, 0, sizeof(z));
+  z.save_max = save_max;
+  z.save_ok = save_max > 0;
+  z.slot_base = slot_base;
+  z.slot_bytes = slot_bytes;
+  z.reloc = reloc;
+  if (reloc) reloc[1] = slot_base;
   z.rtol = rtol;
   z.atol = atol;
   z.n_times = n_times;
@@ -363,13 +398,44 @@ extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int b
   const size_t hid = al256((size_t)batch * max_hidden(f) * kPix * 4);
   const size_t np = (size_t)batch * (f->channels[0] / 32) * 2 * 4;
   return al256(sizeof(DopriState)) + al256((size_t)n_times * 8) + 3 * al256((np > 1024 ? np : 1024) * 4) + 2 * hid + 10 * st +
-         al256(persist_sync_bytes(batch));
+         al256(persist_sync_bytes(batch)) + al256(16 * 8);
 }
+
+// SAVING forward: the plain forward's workspace followed by the backward pass's (dopri5_layout.h) with max_accept slots
+extern "C" size_t odehip_dopri5_saving_workspace_bytes(const odehip_convstack* f, int batch, int n_times, int max_accept) {
+  if (!f || batch <= 0 || n_times <= 0 || max_accept <= 0 || f->n_convs < 1) return 0;
+  return odehip_dopri5_workspace_bytes(f, batch, n_times) + BwdLayout(f, batch, n_times, max_accept).total;
+}
+
+static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch, float rtol,
+                          float atol, double first_step, int max_steps, int negate, float* out_nchw, int* stats_host,
+                          double* accepted_host, int accepted_cap, void* workspace, size_t workspace_bytes, void* stream_,
+                          int save_max_accept, int* saved_out);
 
 extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
                                     int batch, float rtol, float atol, double first_step, int max_steps, int negate,
                                     float* out_nchw, int* stats_host, double* accepted_host, int accepted_cap, void* workspace,
                                     size_t workspace_bytes, void* stream_) {
+  return dopri5_forward(f, z0_nchw, t_host, n_times, batch, rtol, atol, first_step, max_steps, negate, out_nchw, stats_host, accepted_host,
+                        accepted_cap, workspace, workspace_bytes, stream_, 0, nullptr);
+}
+
+extern "C" int odehip_odeint_dopri5_saving(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
+                                           int batch, float rtol, float atol, double first_step, int max_steps, float* out_nchw,
+                                           int* stats_host, double* accepted_host, int accepted_cap, int max_accept, int* saved_out,
+                                           void* workspace, size_t workspace_bytes, void* stream_) {
+  ODEHIP_REQUIRE(saved_out && max_accept > 0, "odeint_dopri5_saving: saved_out is required and max_accept must be positive");
+  *saved_out = 0;
+  ODEHIP_REQUIRE(f && workspace_bytes >= odehip_dopri5_saving_workspace_bytes(f, batch, n_times, max_accept),
+                 "odeint_dopri5_saving: workspace too small");
+  return dopri5_forward(f, z0_nchw, t_host, n_times, batch, rtol, atol, first_step, max_steps, 0, out_nchw, stats_host, accepted_host,
+                        accepted_cap, workspace, workspace_bytes, stream_, max_accept, saved_out);
+}
+
+static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch, float rtol,
+                          float atol, double first_step, int max_steps, int negate, float* out_nchw, int* stats_host,
+                          double* accepted_host, int accepted_cap, void* workspace, size_t workspace_bytes, void* stream_,
+                          int save_max_accept, int* saved_out) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(z0_nchw && t_host && out_nchw && workspace, "odeint_dopri5: null pointer");
@@ -411,7 +477,23 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   float* k[7];
   for (int i = 0; i < 7; ++i) k[i] = (float*)take(st_b);
   unsigned* psync = (unsigned*)take(persist_sync_bytes(batch));
+  unsigned long long* reloc = (unsigned long long*)take(16 * 8);
   const int* skip = &state->done;
+
+  // ---- SAVING mode: every attempt writes its stage inputs and hidden activations into a slot of the backward workspace that
+  // follows this one; the slot is chosen on the device (class-1 relocatable pointers), so the attempt's table is still the same
+  // for every attempt.  Needs the adaptive walk: without it (or for other stacks) nothing is saved and the caller re-integrates.
+  bool saving = false;
+  char* bws = base + al256(odehip_dopri5_workspace_bytes(f, batch, n_times));
+  const BwdLayout BL(f, batch, n_times, save_max_accept > 0 ? save_max_accept : 1);
+  if (save_max_accept > 0 && all_64(f) && !g_reduce_cb && n_times > 1) {
+    PersistScope probe;
+    if ((rc = probe.begin(f, nullptr, 1)) != ODEHIP_OK) return rc;
+    saving = probe.recording();
+  }
+  constexpr unsigned long long kTag1 = 1ull << 56;
+  auto s_xin = [&](int e) { return (float*)(kTag1 | (unsigned long long)((size_t)e * BL.st)); };
+  auto s_hid = [&](int e, int l) { return (float*)(kTag1 | (unsigned long long)(7 * BL.st + ((size_t)e * BL.NH + l) * BL.hid)); };
 
   // exact-global mode: the kernels below read ONE already all-reduced scalar instead of the local partial arrays
   const bool global_norm = g_reduce_cb != nullptr;
@@ -430,7 +512,9 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
     return ODEHIP_OK;
   };
   hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, state, rtol, atol, n_times,
-                     global_norm ? 1 : n_conv_partials, (long long)st_f * (global_norm ? g_reduce_world : 1), max_steps);
+                     global_norm ? 1 : n_conv_partials, (long long)st_f * (global_norm ? g_reduce_world : 1), max_steps,
+                     saving ? save_max_accept : 0, (unsigned long long)(uintptr_t)(bws + BL.off_slots), (unsigned long long)BL.slot_bytes,
+                     saving ? reloc : (unsigned long long*)nullptr);
   for (int o = 0; o < n_times; o += 32) {
     DoublePack p;
     const int m = n_times - o < 32 ? n_times - o : 32;
@@ -441,6 +525,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   ODEHIP_CHECK_HIP(hipMemcpyAsync(out_nchw, z0_nchw, st_b, hipMemcpyDeviceToDevice, stream));  // solution[0] = y0
   rc = odehip_nchw_to_q4(z0_nchw, y, batch, C, stream);
   if (rc != ODEHIP_OK) return rc;
+  if (saving) ODEHIP_CHECK_HIP(hipMemcpyAsync(BL.xin(bws, 0, 0), y, st_b, hipMemcpyDeviceToDevice, stream));   // stage input (0, 0) = z0
   if (n_times == 1) {
     if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
     return ODEHIP_OK;
@@ -452,7 +537,13 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   const float ksc = negate ? -1.0f : 1.0f;
   c.k_scale = ksc;
   c.k_out = k[0];
-  rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
+  if (saving) {   // k1 of the first step = evaluation (slot 0, stage 0): its hidden activations are kept
+    float* hid0[ODEHIP_MAX_LAYERS];
+    for (int l = 0; l < BL.NH; ++l) hid0[l] = BL.hidden(bws, 0, 0, l);
+    rc = enqueue_f_saving(f, y, batch, hid0, ping, pong, &c, nullptr, nullptr, stream);
+  } else {
+    rc = enqueue_f(f, y, batch, ping, pong, &c, nullptr, nullptr, stream);
+  }
   if (rc != ODEHIP_OK) return rc;
   LinComb lc;
   memset(&lc, 0, sizeof(lc));
@@ -491,6 +582,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   }
   lc.c[0] = (float)dp5::kBeta[0][0];
   lc.h_ptr = &state->h;
+  if (saving) lc.out = BL.xin(bws, 0, 1);
   hipLaunchKernelGGL(lincomb_kernel, dim3(1024), dim3(256), 0, stream, lc, n4);  // x2 of the first attempt
   ODEHIP_CHECK_HIP(hipGetLastError());
 
@@ -505,6 +597,8 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
   fa.out_nchw = out_nchw;
   fa.channels = C;
   fa.state_floats = (long long)st_f;
+  fa.off_y1 = (long long)(6 * BL.st);
+  fa.off_x2 = (long long)(1 * BL.st);
 
   // ---- attempted steps; the host runs at most RUN_AHEAD attempts ahead of the device
   // one attempt queued behind the running one keeps the GPU busy (enqueue ~0.1 ms < attempt ~0.4 ms).  Exact-global mode
@@ -528,17 +622,25 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
       c.k_out = k[s - 1];
       if (s <= 6) {
         for (int j = 0; j < s; ++j) c.c1[j] = (float)dp5::kBeta[s - 1][j];
-        c.out1 = s < 6 ? xs : y1;  // x7 = y1 (c_sol equals the last beta row)
+        c.out1 = saving ? s_xin(s) : (s < 6 ? xs : y1);  // x7 = y1 (c_sol equals the last beta row)
       } else {
         for (int j = 0; j < 7; ++j) c.ce[j] = (float)dp5::kCErr[j];
-        c.err_y1 = y1;
+        c.err_y1 = saving ? s_xin(6) : y1;
         c.err_partials = part0;
         c.rtol = rtol;
         c.atol = atol;
       }
-      rc = enqueue_f(f, s < 7 ? xs : y1, batch, ping, pong, &c, nullptr, skip, stream);
+      if (saving) {   // evaluation (slot, s - 1): input and hidden activations live in the slot the device picks
+        ODEHIP_REQUIRE(persist.recording(), "odeint_dopri5: the persistent walk became unavailable during a saving forward");
+        float* hid_s[ODEHIP_MAX_LAYERS];
+        for (int l = 0; l < BL.NH; ++l) hid_s[l] = s_hid(s - 1, l);
+        rc = enqueue_f_saving(f, s_xin(s - 1), batch, hid_s, ping, pong, &c, nullptr, skip, stream);
+      } else {
+        rc = enqueue_f(f, s < 7 ? xs : y1, batch, ping, pong, &c, nullptr, skip, stream);
+      }
       if (rc != ODEHIP_OK) return rc;
     }
+    if (saving) persist.set_device_steering(nullptr, reloc);
     if ((rc = persist.finish(nullptr, nullptr, nullptr, batch, psync, f->ks, stream)) != ODEHIP_OK) return rc;
     if (global_norm) {
       const float* arr[1] = {part0};
@@ -580,6 +682,7 @@ extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_n
               "Persistent launches are now disabled for this process", code);
     return ODEHIP_EHIP;
   }
+  if (saved_out) *saved_out = saving && g_mailbox->save_ok && g_mailbox->status == 0;
   if (stats_host) {
     stats_host[0] = g_mailbox->nfe;
     stats_host[1] = g_mailbox->n_accept;

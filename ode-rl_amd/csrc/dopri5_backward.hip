@@ -21,49 +21,13 @@
 
 #include "odehip_internal.h"
 #include "persist.h"
+#include "dopri5_layout.h"
 
 namespace odehip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-
-struct BwdLayout {
-  int T, B, C, NH, N;
-  size_t st, hid, slot_bytes;
-  size_t off_h, off_ping, off_pong, off_go, off_k, off_gY, off_gy, off_gk1, off_slots, off_tab, off_psync, off_slab, total;
-  BwdLayout(const odehip_convstack* f, int batch, int n_times, int n_steps) {
-    T = n_times; B = batch; C = f->channels[0]; NH = f->n_convs - 1; N = n_steps;
-    st = al256((size_t)B * C * kPix * 4);
-    int cmax = 32;
-    for (int i = 0; i <= f->n_convs; ++i) cmax = f->channels[i] > cmax ? f->channels[i] : cmax;
-    hid = al256((size_t)B * cmax * kPix * 4);
-    slot_bytes = 7 * (st + (size_t)NH * hid + (size_t)(NH + 1) * hid);
-    size_t o = 0;
-    auto take = [&](size_t b) { size_t r = o; o += al256(b); return r; };
-    off_h = take((size_t)(N > 0 ? N : 1) * 4);
-    off_ping = take(hid);
-    off_pong = take(hid);
-    off_go = take((size_t)T * st);
-    off_k = take(7 * st);
-    off_gY = take(7 * st);
-    off_gy = take(2 * st);
-    off_gk1 = take(2 * st);
-    off_slots = take((size_t)(N > 0 ? N : 1) * slot_bytes);
-    off_tab = take(((size_t)N * 6 + 1) * sizeof(WgradPair) * ODEHIP_MAX_LAYERS);
-    off_psync = take(persist_sync_bytes(B));
-    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
-    total = o;
-  }
-  float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }
-  float* xin(void* ws, int n, int s) const { return p(ws, off_slots + (size_t)n * slot_bytes + (size_t)s * st); }
-  float* hidden(void* ws, int n, int s, int l) const {
-    return p(ws, off_slots + (size_t)n * slot_bytes + 7 * st + ((size_t)s * NH + l) * hid);
-  }
-  float* gp(void* ws, int n, int s, int l) const {
-    return p(ws, off_slots + (size_t)n * slot_bytes + 7 * st + 7 * (size_t)NH * hid + ((size_t)s * (NH + 1) + l) * hid);
-  }
-};
 
 }  // namespace odehip
 
@@ -74,14 +38,44 @@ extern "C" size_t odehip_dopri5_backward_workspace_bytes(const odehip_convstack*
   return BwdLayout(f, batch, n_times, n_steps).total;
 }
 
+// layout_steps: the number of slots the workspace was laid out for (n_steps, or the saving forward's max_accept); saved: the
+// slots already hold the stage inputs and hidden activations of the accepted steps (odehip_odeint_dopri5_saving): no re-integration
+static int dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host, int n_times, int batch,
+                           const double* accepted_host, int n_steps, const float* z0_nchw, const float* grad_out_nchw,
+                           float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, void* workspace, size_t workspace_bytes,
+                           void* stream_, int layout_steps, bool saved);
+
 extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host,
                                              int n_times, int batch, const double* accepted_host, int n_steps,
                                              const float* z0_nchw, const float* grad_out_nchw, float* grad_z0_nchw,
                                              float* const* grad_w, float* const* grad_b, void* workspace, size_t workspace_bytes,
                                              void* stream_) {
+  ODEHIP_REQUIRE(z0_nchw, "odeint_dopri5_backward: null pointer");
+  return dopri5_backward(f, f_dgrad, t_host, n_times, batch, accepted_host, n_steps, z0_nchw, grad_out_nchw, grad_z0_nchw, grad_w, grad_b,
+                         workspace, workspace_bytes, stream_, n_steps, false);
+}
+
+extern "C" int odehip_odeint_dopri5_backward_saved(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host,
+                                                   int n_times, int batch, const double* accepted_host, int n_steps,
+                                                   const float* grad_out_nchw, float* grad_z0_nchw, float* const* grad_w,
+                                                   float* const* grad_b, int max_accept, void* saved_workspace,
+                                                   size_t saved_workspace_bytes, void* stream_) {
+  ODEHIP_REQUIRE(f && saved_workspace && max_accept > 0 && n_steps >= 1 && n_steps <= max_accept,
+                 "odeint_dopri5_backward_saved: needs the saving forward's workspace and 1 <= n_steps <= max_accept");
+  ODEHIP_REQUIRE(saved_workspace_bytes >= odehip_dopri5_saving_workspace_bytes(f, batch, n_times, max_accept),
+                 "odeint_dopri5_backward_saved: workspace smaller than the saving forward's");
+  char* bws = (char*)saved_workspace + al256(odehip_dopri5_workspace_bytes(f, batch, n_times));   // the backward half (dopri5.hip)
+  return dopri5_backward(f, f_dgrad, t_host, n_times, batch, accepted_host, n_steps, nullptr, grad_out_nchw, grad_z0_nchw, grad_w, grad_b,
+                         bws, saved_workspace_bytes - (size_t)(bws - (char*)saved_workspace), stream_, max_accept, true);
+}
+
+static int dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_dgrad, const double* t_host, int n_times, int batch,
+                           const double* accepted_host, int n_steps, const float* z0_nchw, const float* grad_out_nchw,
+                           float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, void* workspace, size_t workspace_bytes,
+                           void* stream_, int layout_steps, bool saved) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
-  ODEHIP_REQUIRE(f_dgrad && t_host && z0_nchw && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace,
+  ODEHIP_REQUIRE(f_dgrad && t_host && (z0_nchw || saved) && grad_out_nchw && grad_z0_nchw && grad_w && grad_b && workspace,
                  "odeint_dopri5_backward: null pointer");
   ODEHIP_REQUIRE(n_times >= 1 && batch > 0 && n_steps >= 0, "odeint_dopri5_backward: bad sizes");
   ODEHIP_REQUIRE(n_steps == 0 || accepted_host, "odeint_dopri5_backward: null step log");
@@ -91,7 +85,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
   for (int i = 1; i < n_times; ++i)
     ODEHIP_REQUIRE(t_host[i] > t_host[i - 1], "odeint_dopri5_backward: t must be strictly increasing");
   ODEHIP_REQUIRE(6 * n_steps + 1 <= 32 * 64, "odeint_dopri5_backward: too many accepted steps (%d)", n_steps);
-  const BwdLayout L(f, batch, n_times, n_steps);
+  const BwdLayout L(f, batch, n_times, layout_steps);
   ODEHIP_REQUIRE(workspace_bytes >= L.total, "odeint_dopri5_backward: workspace too small");
   hipStream_t stream = (hipStream_t)stream_;
   void* ws = workspace;
@@ -127,7 +121,7 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
   rc = odehip_nchw_to_q4(grad_out_nchw, goq(0), n_times * batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
   if (N == 0) {  // a single output time: out[0] = z0
-    ODEHIP_REQUIRE(n_times == 1, "odeint_dopri5_backward: empty step log");
+    ODEHIP_REQUIRE(n_times == 1 && !saved, "odeint_dopri5_backward: empty step log");
     ODEHIP_CHECK_HIP(hipMemcpyAsync(grad_z0_nchw, grad_out_nchw, st_b, hipMemcpyDeviceToDevice, stream));
     for (int l = 0; l < NL; ++l) {
       ODEHIP_CHECK_HIP(hipMemsetAsync(grad_w[l], 0, (size_t)f->channels[l + 1] * f->channels[l] * 9 * 4, stream));
@@ -147,8 +141,10 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
   // same rows are replayed as ordinary launches, with bit-identical results.
   const bool order1 = all_64(f);   // order-1 stage combines are what the adaptive walk takes (other stacks: one launch per layer)
   ODEHIP_CHECK_HIP(hipMemsetAsync(L.p(ws, L.off_gy), 0, st_b, stream));   // (before the rows: everything recorded runs at finish())
-  rc = odehip_nchw_to_q4(z0_nchw, L.xin(ws, 0, 0), batch, L.C, stream);
-  if (rc != ODEHIP_OK) return rc;
+  if (!saved) {
+    rc = odehip_nchw_to_q4(z0_nchw, L.xin(ws, 0, 0), batch, L.C, stream);
+    if (rc != ODEHIP_OK) return rc;
+  }
   int n_out_max = 1;
   for (int n = 0; n < N; ++n) n_out_max = j_hi[n] - j_lo[n] > n_out_max ? j_hi[n] - j_lo[n] : n_out_max;
   const int ew_per_seed = (n_out_max + 6 + ODEHIP_MAX_STAGES) / ODEHIP_MAX_STAGES + 1;
@@ -200,8 +196,8 @@ extern "C" int odehip_odeint_dopri5_backward(const odehip_convstack* f, const od
   c.h_ptr = hdev;
   c.c1[0] = (float)dp5::kBeta[0][0];
   c.out1 = L.xin(ws, 0, 1);
-  if ((rc = run_f(0, 0, L.xin(ws, 0, 0), c)) != ODEHIP_OK) return rc;  // k1 of the first step (+ its Y_2)
-  for (int n = 0; n < N; ++n) {
+  if (!saved && (rc = run_f(0, 0, L.xin(ws, 0, 0), c)) != ODEHIP_OK) return rc;  // k1 of the first step (+ its Y_2)
+  for (int n = 0; n < N && !saved; ++n) {
     const float* y0 = n == 0 ? L.xin(ws, 0, 0) : L.xin(ws, n - 1, 6);
     for (int s = 2; s <= 7; ++s) {
       memset(&c, 0, sizeof(c));

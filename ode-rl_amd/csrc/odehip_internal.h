@@ -60,6 +60,8 @@ struct CombineArgs {
   // holds three partial sums instead of up to six earlier stages), and every kernel that evaluates the expression rounds it the
   // same way (no contraction left to the compiler), so the walk stays bit-identical to one launch per layer.
   int order;
+  const float* c_dev;   // elementwise rows only: if non-null, c1[j] is read from this DEVICE array instead (coefficients a device-side
+                        // controller computed, e.g. the dense-output weights of an accepted step)
 };
 // ---- elementwise rows (ConvArgs::combine == 4): no convolution.  Uses the CombineArgs fields:
 //   out1 = (y ? y : 0) + sum_{j < n_prev} (c1[j] * hs) * k_prev[j]        hs = *h_ptr (1 if null)
@@ -119,8 +121,9 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
                               unsigned* host_err_dev, int grid, hipStream_t stream);
 int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
                         float* out_nchw, int grid, hipStream_t stream, bool wide = false,  // wide: the table has 128-channel layers
-                        bool adaptive = false, const int* n_layers_ptr = nullptr);          // adaptive: wino_persist_d_kernel (order-1
-                                                                                            // combines, elementwise rows, h on the device)
+                        bool adaptive = false, const int* n_layers_ptr = nullptr,           // adaptive: wino_persist_d_kernel (order-1
+                        const unsigned long long* reloc = nullptr);                         // combines, elementwise rows, h on the device;
+                                                                                            // {row0, rows} and relocation bases on the device)
 int launch_ew_row(const ConvArgs& a, hipStream_t stream);   // an elementwise row (combine == 4) as an ordinary launch
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_wino5(const ConvArgs& a, hipStream_t stream);  // 5x5 layers with a.w_wino (conv_wino5.hip); 1 = no such form, run the direct kernel

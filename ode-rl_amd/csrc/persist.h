@@ -26,6 +26,17 @@ class PersistScope {
   // adaptive solve): it is uploaded asynchronously through a ring instead of entering the content cache (whose misses cost a
   // stream synchronisation).  Call between begin() and finish().
   void set_volatile_table(bool v) { volatile_ = v; }
+  // The recorded rows are a TEMPLATE a device-side controller steers: rows_dev = {first row, number of rows} of the section the
+  // launch walks, reloc_dev = the base addresses of the relocatable pointers in the rows (class << 56 | offset; conv_wino.hip,
+  // rel()).  Such a table only runs on the adaptive walk (callers check recording() first and take their host-driven path
+  // otherwise): finish() fails with ODEHIP_EHIP rather than replaying it.
+  void set_device_steering(const int* rows_dev, const unsigned long long* reloc_dev) {
+    rows_dev_ = rows_dev;
+    reloc_dev_ = reloc_dev;
+    adaptive_ = true;
+  }
+  // true if begin() found the persistent path usable for this stack (the recorder is on)
+  bool recording() const { return active_; }
   // hbuf / hdev: host copy and device array of the step sizes (fixed grids: the table gets h by value), or null / null when the
   // step size only exists on the device (dopri5); out_nchw may be null; sync: persist_sync_bytes(batch) of workspace
   // sync_is_zero: the caller has already zeroed the flag area on this stream (traj_prologue)
@@ -45,6 +56,8 @@ class PersistScope {
   bool small_ = false;
   bool adaptive_ = false;
   bool volatile_ = false;
+  const int* rows_dev_ = nullptr;
+  const unsigned long long* reloc_dev_ = nullptr;
   bool launched_ = false;
   const unsigned* abort_word_ = nullptr;
 };

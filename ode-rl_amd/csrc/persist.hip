@@ -352,7 +352,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
-                               kPersistGrid, stream, wide, adaptive, nullptr);
+                               kPersistGrid, stream, wide, adaptive, rows_dev_, reloc_dev_);
       if (volatile_) persist_table_async_done(stream);
       if (rc == ODEHIP_OK) {
         ++g_persist.launches;
@@ -362,6 +362,10 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
       }
       g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
       (void)hipGetLastError();
+    }
+    if (rows_dev_ || reloc_dev_) {
+      set_error("the persistent walk refused a device-steered table (%d rows): it cannot be replayed as ordinary launches", rec_.count);
+      return ODEHIP_EHIP;
     }
     for (int i = 0; i < rec_.count; ++i) {  // replay the recorded layers as ordinary launches
       ConvArgs a = rec_.items[i];

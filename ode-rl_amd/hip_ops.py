@@ -475,6 +475,71 @@ def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=
                  "accepted": [(log[2 * i], log[2 * i + 1]) for i in range(k)]}
 
 
+_dopri5_save_slots = 8   # slots of a saving forward's workspace; doubled (up to 64) after a forward that accepted more steps
+
+
+def odeint_dopri5_saving(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
+    """The forward of a dopri5 TRAINING step: odeint_dopri5 that also keeps the stage inputs and hidden activations of every accepted
+    step in a private workspace, so that the backward pass needs no re-integration.  Returns (out, stats, saved) with saved =
+    (workspace, max_accept), or None when nothing was kept (other stacks than 64-channel fp32, persistent walk off, more accepted
+    steps than slots): the caller then takes odeint_dopri5_backward."""
+    global _dopri5_save_slots
+    if os.environ.get("ODEHIP_DOPRI5_SAVE") == "0":   # A/B switch: always re-integrate in the backward pass
+        out, st = odeint_dopri5(stack, z0, t, rtol, atol, first_step=first_step, max_steps=max_steps)
+        st["saved"] = False
+        return out, st, None
+    require_device_tensor(z0, "y0")
+    desc = stack.refresh()
+    z0 = z0.contiguous()
+    b, c = z0.shape[0], z0.shape[1]
+    if z0.dim() != 4 or tuple(z0.shape[2:]) != (16, 16) or c != desc.channels[0]:
+        raise ValueError(f"y0 must be (B,{desc.channels[0]},16,16) (got {tuple(z0.shape)})")
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n = len(t64)
+    lib = _lib.load()
+    slots = _dopri5_save_slots
+    nbytes = lib.odehip_dopri5_saving_workspace_bytes(ctypes.byref(desc), b, n, slots)
+    ws = alloc_workspace(nbytes, z0.device)   # private: it must survive untouched until backward
+    out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
+    tarr = (ctypes.c_double * n)(*t64)
+    stats = (ctypes.c_int * 4)()
+    log = (ctypes.c_double * (2 * LOG_CAP))()
+    saved = ctypes.c_int(0)
+    _lib.check(lib.odehip_odeint_dopri5_saving(ctypes.byref(desc), _ptr(z0), tarr, n, b, float(rtol), float(atol), float(first_step or 0.0),
+                                               int(max_steps), _ptr(out), stats, log, LOG_CAP, slots, ctypes.byref(saved), _ptr(ws), ws.numel(),
+                                               _stream()))
+    k = min(int(stats[1]), LOG_CAP)
+    if int(stats[1]) > slots:
+        _dopri5_save_slots = min(64, max(2 * slots, int(stats[1]) + 2))
+    st = {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3],
+          "accepted": [(log[2 * i], log[2 * i + 1]) for i in range(k)], "saved": bool(saved.value)}
+    return out, st, ((ws, slots) if saved.value else None)
+
+
+def odeint_dopri5_backward_saved(stack, t, accepted, grad_out, saved):
+    """Backward of odeint_dopri5_saving: the reverse sweep over the kept activations (no re-integration)."""
+    require_device_tensor(grad_out, "grad_out")
+    ws, slots = saved
+    desc = stack.refresh()
+    dg = stack.dgrad_desc()
+    grad_out = grad_out.contiguous()
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n, b, c = len(t64), grad_out.shape[1], desc.channels[0]
+    lib = _lib.load()
+    gz0 = torch.empty((b, c, 16, 16), dtype=torch.float32, device=grad_out.device)
+    gws = [torch.empty_like(cv.weight) for cv in stack.convs]
+    gbs = [torch.empty_like(cv.bias) for cv in stack.convs]
+    nl = len(gws)
+    gw_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gws])
+    gb_arr = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in gbs])
+    tarr = (ctypes.c_double * n)(*t64)
+    flat = [v for pair in accepted for v in pair]
+    larr = (ctypes.c_double * max(len(flat), 1))(*flat)
+    _lib.check(lib.odehip_odeint_dopri5_backward_saved(ctypes.byref(desc), ctypes.byref(dg), tarr, n, b, larr, len(accepted), _ptr(grad_out),
+                                                       _ptr(gz0), gw_arr, gb_arr, int(slots), _ptr(ws), ws.numel(), _stream()))
+    return gz0, gws, gbs
+
+
 def odeint_dopri5_backward(stack, t, accepted, z0, grad_out):
     """Gradient of the accepted dopri5 steps (what autograd through torchdiffeq computes): (grad_z0, [grad_w], [grad_b])."""
     require_device_tensor(grad_out, "grad_out")

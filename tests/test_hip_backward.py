@@ -347,3 +347,62 @@ def test_config2_dopri5_adjoint_batch8_full_grid(cuda):
     for i, (c, gw, gb) in enumerate(zip(convs, ref_gp[:5], ref_gp[5:])):
         errs += [record(f"config2.grad_w{i}", rel_l2(c.weight.grad, gw)), record(f"config2.grad_b{i}", rel_l2(c.bias.grad, gb))]
     assert max(errs) <= 1e-4, errs
+
+
+@pytest.mark.parametrize("first_step,batch", [(0.3, 3), (None, 64)])
+def test_dopri5_saving_forward_equals_reintegration(cuda, first_step, batch):
+    """Round 3: the forward of a dopri5 training step keeps the activations of the accepted steps in slots chosen ON THE DEVICE
+    (rejected attempts reuse their slot -- first_step 0.3 forces rejections), the backward walks them without re-integrating.
+    Against the re-integrating backward (ODEHIP_DOPRI5_SAVE=0) on the same inputs: same step sequence, gradients <= 1e-5 (the
+    stage-2 input of a step is rounded differently by the two paths, nothing else differs); and a forward that accepts more steps
+    than it has slots reports saved = False and still yields the re-integrating path's gradients bit for bit."""
+    import os
+    import ode_rl_amd
+    from ode_rl_amd import hip_ops
+    if os.environ.get("ODEHIP_PERSISTENT") == "0":
+        pytest.skip("the saving forward needs the persistent walk")
+    f, _ = _kink_free()
+    f = f.to(cuda)
+    g = torch.Generator().manual_seed(41)
+    z0 = (torch.randn(batch, 64, 16, 16, generator=g) * 0.5).to(cuda)
+    t = torch.tensor([0.1, 0.25, 0.3, 0.7], dtype=torch.float64)
+    gout = torch.randn(4, batch, 64, 16, 16, generator=g).to(cuda)
+    opts = {"first_step": first_step} if first_step else None
+
+    def run():
+        f.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        sol = ode_rl_amd.odeint(f, z, t, rtol=1e-5 if first_step else 1e-3, atol=1e-6 if first_step else 1e-4, method="dopri5", options=opts)
+        st = dict(ode_rl_amd.last_stats)
+        sol.backward(gout)
+        return sol.detach().clone(), z.grad.clone(), [p.grad.clone() for p in f.parameters()], st
+
+    old = os.environ.get("ODEHIP_DOPRI5_SAVE")
+    slots = hip_ops._dopri5_save_slots
+    try:
+        os.environ["ODEHIP_DOPRI5_SAVE"] = "0"
+        s0, gz0, gp0, st0 = run()
+        os.environ.pop("ODEHIP_DOPRI5_SAVE")
+        s1, gz1, gp1, st1 = run()
+        assert st1["saved"] and not st0["saved"]
+        assert (st1["nfe"], st1["n_accept"], st1["n_reject"]) == (st0["nfe"], st0["n_accept"], st0["n_reject"])
+        if first_step:
+            assert st1["n_reject"] >= 1 and st1["n_accept"] >= 2
+        assert torch.equal(s1, s0)                       # the forward's arithmetic is untouched by saving
+        assert record(f"dopri5.saved.grad_z0.B{batch}", rel_l2(gz1, gz0)) <= 1e-5
+        for i, (a, b) in enumerate(zip(gp1, gp0)):
+            assert record(f"dopri5.saved.grad_p{i}.B{batch}", rel_l2(a, b)) <= 1e-5
+        s1b, gz1b, gp1b, _ = run()
+        assert torch.equal(gz1b, gz1) and all(torch.equal(a, b) for a, b in zip(gp1b, gp1))   # deterministic
+        if st1["n_accept"] >= 2:
+            hip_ops._dopri5_save_slots = 1               # fewer slots than accepted steps
+            s2, gz2, gp2, st2 = run()
+            assert not st2["saved"] and torch.equal(s2, s0)
+            assert torch.equal(gz2, gz0) and all(torch.equal(a, b) for a, b in zip(gp2, gp0))
+            assert hip_ops._dopri5_save_slots >= st2["n_accept"]     # the next forward gets enough
+    finally:
+        hip_ops._dopri5_save_slots = slots
+        if old is None:
+            os.environ.pop("ODEHIP_DOPRI5_SAVE", None)
+        else:
+            os.environ["ODEHIP_DOPRI5_SAVE"] = old
