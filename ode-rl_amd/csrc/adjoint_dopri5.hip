@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "odehip_internal.h"
+#include "adjoint_layout.h"
 
 namespace odehip {
 
@@ -128,50 +129,6 @@ __global__ __launch_bounds__(256) void theta_add_kernel(float* __restrict__ a, c
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) a[i] += d[i];
 }
 
-struct AdjLayout {
-  int T, B, C, NH, max_slots, n_part;
-  size_t st, hid, slot_bytes;
-  size_t off_h, off_part, off_sums, off_ping, off_pong, off_y, off_go, off_a2, off_ky, off_ka, off_slots, off_tab, off_slab, off_theta, total;
-  int P;  // floats of the flattened parameter vector (w0, b0, w1, b1, ...)
-  AdjLayout(const odehip_convstack* f, int batch, int n_times, int max_accept) {
-    T = n_times; B = batch; C = f->channels[0]; NH = f->n_convs - 1; max_slots = max_accept + 1;
-    st = al256((size_t)B * C * kPix * 4);
-    int cmax = 32;
-    for (int i = 0; i <= f->n_convs; ++i) cmax = f->channels[i] > cmax ? f->channels[i] : cmax;
-    hid = al256((size_t)B * cmax * kPix * 4);
-    n_part = B * (C / 32) * 2 * 4;
-    slot_bytes = 7 * (st + (size_t)NH * hid + (size_t)(NH + 1) * hid);
-    size_t o = 0;
-    auto take = [&](size_t b) { size_t r = o; o += al256(b); return r; };
-    off_h = take(256);
-    off_part = take(8 * (size_t)(n_part > 256 ? n_part : 256) * 4);
-    off_sums = take(256);
-    off_ping = take(hid);
-    off_pong = take(hid);
-    off_y = take((size_t)T * st);
-    off_go = take((size_t)T * st);
-    off_a2 = take(2 * st);
-    off_ky = take(7 * st);
-    off_ka = take(7 * st);
-    off_slots = take((size_t)max_slots * slot_bytes);
-    off_tab = take((size_t)max_slots * 7 * sizeof(WgradPair));
-    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
-    P = 0;
-    for (int l = 0; l < f->n_convs; ++l) P += f->channels[l + 1] * f->channels[l] * 9 + f->channels[l + 1];
-    off_theta = take((size_t)5 * P * 4);  // mixed norm: running a_theta, error estimate, increment, K^theta at the two initial-step points
-    total = o;
-  }
-  float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }
-  float* xin(void* ws, int slot, int s) const { return p(ws, off_slots + (size_t)slot * slot_bytes + (size_t)s * st); }
-  float* hidden(void* ws, int slot, int s, int l) const {
-    return p(ws, off_slots + (size_t)slot * slot_bytes + 7 * st + ((size_t)s * NH + l) * hid);
-  }
-  float* gp(void* ws, int slot, int s, int l) const {
-    return p(ws, off_slots + (size_t)slot * slot_bytes + 7 * st + 7 * (size_t)NH * hid + ((size_t)s * (NH + 1) + l) * hid);
-  }
-  float* part(void* ws, int j) const { return p(ws, off_part + (size_t)j * (n_part > 256 ? n_part : 256) * 4); }
-};
-
 static float* g_adj_host = nullptr;  // 256 B of pinned host memory for the per-attempt scalars
 
 }  // namespace odehip
@@ -222,6 +179,14 @@ extern "C" int odehip_odeint_adjoint_dopri5_backward(const odehip_convstack* f, 
   auto yq = [&](int n) { return L.p(ws, L.off_y + (size_t)n * L.st); };
   auto goq = [&](int n) { return L.p(ws, L.off_go + (size_t)n * L.st); };
 
+  if (!mixed_norm && n_times > 1) {
+    // seminorm on a 64-channel fp32 stack: step control on the device, evaluations on the adaptive persistent walk
+    // (adjoint_device.hip); `ran` = 0 when that path is not available here -- the host loop below then takes the call
+    int ran = 0;
+    rc = adjoint_dopri5_device(f, f_dgrad, t_host, n_times, batch, rtol, atol, y_traj_nchw, grad_out_nchw, grad_z0_nchw, grad_w, grad_b,
+                               max_accept, stats_host, workspace, workspace_bytes, stream, &ran);
+    if (rc != ODEHIP_OK || ran) return rc;
+  }
   rc = odehip_nchw_to_q4(y_traj_nchw, yq(0), n_times * batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
   rc = odehip_nchw_to_q4(grad_out_nchw, goq(0), n_times * batch, L.C, stream);

@@ -47,6 +47,9 @@ class PersistScope {
   // invalid result cannot hand plausible-looking numbers to its caller.  No-op when nothing was launched persistently.
   int guard(float* const* regions, const size_t* floats, int n, hipStream_t stream);
   bool launched() const { return launched_; }
+  // Launch the table of the last finish() AGAIN (a device-steered table is walked once per tick of its controller).  Only after a
+  // finish() that took the persistent path; sync as for finish().
+  int relaunch(int batch, unsigned* sync, hipStream_t stream, bool sync_is_zero);
 
  private:
   std::unique_lock<std::mutex> lock_;
@@ -60,6 +63,9 @@ class PersistScope {
   const unsigned long long* reloc_dev_ = nullptr;
   bool launched_ = false;
   const unsigned* abort_word_ = nullptr;
+  const ConvArgs* table_ = nullptr;   // device table of the last persistent launch
+  int table_rows_ = 0;
+  bool table_wide_ = false, table_adaptive_ = false;
 };
 
 // Whole-trajectory launches that need no cross-workgroup hand-off (bf16: one workgroup per sample) obey the same on/off switch

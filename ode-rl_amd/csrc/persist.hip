@@ -358,6 +358,10 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
         ++g_persist.launches;
         launched_ = true;
         abort_word_ = sync + (size_t)batch * kPersistDoneStride + kPersistGrid;   // xcc_of[grid]: zeroed above, epoch 0 => tag 1
+        table_ = table;
+        table_rows_ = rec_.count;
+        table_wide_ = wide;
+        table_adaptive_ = adaptive;
         return rc;
       }
       g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
@@ -377,6 +381,15 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     }
     return ODEHIP_OK;
   }
+
+int PersistScope::relaunch(int batch, unsigned* sync, hipStream_t stream, bool sync_is_zero) {
+  ODEHIP_REQUIRE(launched_ && table_ && !volatile_, "persistent relaunch without a table");
+  if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
+  const int rc = launch_wino_persist(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
+                                     kPersistGrid, stream, table_wide_, table_adaptive_, rows_dev_, reloc_dev_);
+  if (rc == ODEHIP_OK) ++g_persist.launches;
+  return rc;
+}
 
 }  // namespace odehip
 
