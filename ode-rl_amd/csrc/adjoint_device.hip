@@ -12,14 +12,16 @@
 //     final weight-gradient launch, the state pointers (y, a) that move with FSAL, the k1 / k7 buffers that swap;
 //   * a TICK = adj_control_kernel (one workgroup: digests the sums of the previous tick -- norms or error partials in fixed order --
 //     takes the decision in torchdiffeq's types, appends the accepted step's stage evaluations to the per-layer weight-gradient
-//     tables, writes {first row, rows} of the next program and the relocation bases, zeroes the walk's flag area) -> the walk ->
-//     adj_norms_kernel (the scaled sums of squares the initial-step search needs; a no-op after other programs);
+//     tables, writes {first row, rows} of the next program and the relocation bases, zeroes the walk's flag area) -> the walk
+//     (the scaled sums of squares of the initial-step search are NORM ROWS at the end of P0 / P1: per-wave partials, no launch);
 //   * the host only bounds its run-ahead by polling a pinned mailbox (one tick ahead) and, after `done`, launches the weight
 //     gradients (one launch per layer over every recorded stage evaluation, as before) with the entry count it reads there.
 // A training step at B=64, T=10 is 27 ticks instead of ~720 per-layer launches and 27 stream synchronisations.
 #include <math.h>
 #include <string.h>
 #include <time.h>
+
+#include <vector>
 
 #include "adjoint_layout.h"
 #include "odehip_internal.h"
@@ -64,19 +66,21 @@ struct AdjMailbox {  // pinned host memory
   int pad_[9];
 };
 
-// fixed-order sum of n floats; valid in thread 0 (the order of adj_reduce_kernel in adjoint_dopri5.hip)
-__device__ float adj_block_sum(const float* v, int n, float* sh) {
-  float s = 0.0f;
-  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
+// Fixed-order sums of up to four arrays of n floats at once: wave w adds array w (lane i takes elements i, i + 64, ...; then a
+// butterfly over the lanes) -- one pass instead of four block reductions behind each other.  Valid in every thread afterwards.
+__device__ void adj_sums4(const float* base, int stride, const int* which, int count, int n, float* sh, float* out) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (w < count) {
+    const float* v = base + (size_t)which[w] * stride;
+    float s = 0.0f;
+    for (int i = lane; i < n; i += 64) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) sh[w] = s;
   }
-  const float r = sh[0];
   __syncthreads();
-  return r;
+  for (int j = 0; j < count; ++j) out[j] = sh[j];
+  __syncthreads();
 }
 
 __device__ double adj_dense_weight(const AdjCtl* st, int s, double x) {  // dp5::dense_weight
@@ -87,27 +91,40 @@ __device__ double adj_dense_weight(const AdjCtl* st, int s, double x) {  // dp5:
   return x * d1 + x * x * C2 + x * x * x * B3 + x * x * x * x * A4;
 }
 
-__global__ __launch_bounds__(256) void adj_control_kernel(AdjCtl* st, const float* parts, int part_stride, unsigned* psync,
+__device__ void adj_decide(AdjCtl* st, float s0, float s1, float s2, float s3, AdjMailbox* mb);
+
+__global__ __launch_bounds__(256) void adj_control_kernel(AdjCtl* st_global, const float* parts, int part_stride, unsigned* psync,
                                                           int psync_words, AdjMailbox* mb) {
   __shared__ float sh[256];
+  // the state is worked on in LDS: thread 0's decision logic touches ~100 of its fields one after the other -- from global memory that
+  // was 11 us per tick (a dependent round trip each), from LDS it is the block sums that set the time
+  __shared__ AdjCtl st_lds;
+  static_assert(sizeof(AdjCtl) % 16 == 0, "copied as 16-byte words");
+  for (int i = threadIdx.x; i < (int)(sizeof(AdjCtl) / 16); i += 256) ((f32x4*)&st_lds)[i] = ((const f32x4*)st_global)[i];
   for (int i = threadIdx.x; i < psync_words; i += 256) psync[i] = 0u;  // the flag area of this tick's walk
+  __syncthreads();
+  AdjCtl* const st = &st_lds;
   const int phase = st->phase;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (!st->done) {
-    if (phase == PH_P0) {
-      s0 = adj_block_sum(parts + 0 * part_stride, 256, sh);
-      s1 = adj_block_sum(parts + 1 * part_stride, 256, sh);
-      s2 = adj_block_sum(parts + 2 * part_stride, 256, sh);
-      s3 = adj_block_sum(parts + 3 * part_stride, 256, sh);
-    } else if (phase == PH_P1) {
-      s0 = adj_block_sum(parts + 0 * part_stride, 256, sh);
-      s1 = adj_block_sum(parts + 1 * part_stride, 256, sh);
-    } else if (phase == PH_P2) {
-      s0 = adj_block_sum(parts + 4 * part_stride, st->n_part, sh);
-      s1 = adj_block_sum(parts + 5 * part_stride, st->n_part, sh);
-    }
+  float sv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!st->done) {   // (uniform) the sums the walk of the previous tick left: per-wave partials, added in a fixed order
+    const int np = st->n_part;
+    const int w0[4] = {0, 1, 2, 3}, w2[4] = {4, 5, 0, 0};
+    if (phase == PH_P0) adj_sums4(parts, part_stride, w0, 4, np, sh, sv);
+    else if (phase == PH_P1) adj_sums4(parts, part_stride, w0, 2, np, sh, sv);
+    else if (phase == PH_P2) adj_sums4(parts, part_stride, w2, 2, np, sh, sv);
   }
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x == 0) adj_decide(st, sv[0], sv[1], sv[2], sv[3], mb);
+  __syncthreads();
+  constexpr int kLive = (int)(offsetof(AdjCtl, t) / 16);   // everything in front of the (constant) time grid goes back
+  static_assert(offsetof(AdjCtl, t) % 16 == 0, "copied as 16-byte words");
+  for (int i = threadIdx.x; i < kLive; i += 256) ((f32x4*)st_global)[i] = ((const f32x4*)&st_lds)[i];
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((int*)&mb->ticks, st->ticks, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the decision logic of a tick (one thread, state in LDS)
+__device__ void adj_decide(AdjCtl* st, float s0, float s1, float s2, float s3, AdjMailbox* mb) {
+  const int phase = st->phase;
   const double N = st->n_elems;
   auto rms = [&](float s) { return sqrtf((float)((double)s / N)); };
   const unsigned long long ST = st->st_bytes;
@@ -270,57 +287,6 @@ __global__ __launch_bounds__(256) void adj_control_kernel(AdjCtl* st, const floa
   mb->n_entries = st->n_entries;
   mb->status = st->status;
   mb->done = st->done;
-  __hip_atomic_store((int*)&mb->ticks, st->ticks, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// The scaled sums of squares of the initial-step search, behind the walk of a P0 / P1 tick (adj_sumsq_kernel's arithmetic and
-// partial layout: sum over elements of ((a - b) / (atol + |y| * rtol))^2, one partial per workgroup).
-//   P0: [0] y, [1] a, [2] k1_y, [3] k1_a          P1: [0] k_y(Euler point) - k1_y, [1] k_a(Euler point) - k1_a
-__global__ __launch_bounds__(256) void adj_norms_kernel(const AdjCtl* st, float* parts, int part_stride, long long n4) {
-  __shared__ float sh[256];
-  const int phase = st->phase;
-  if (phase != PH_P0 && phase != PH_P1) return;
-  const float atol = st->atol, rtol = st->rtol;
-  const unsigned long long ST = st->st_bytes;
-  const f32x4* y = (const f32x4*)st->reloc[RC_Y];
-  const f32x4* a = (const f32x4*)st->reloc[RC_A];
-  const f32x4* k1y = (const f32x4*)st->reloc[RC_KYA];
-  const f32x4* k1a = (const f32x4*)st->reloc[RC_KAA];
-  const f32x4* k2y = (const f32x4*)(st->ky_base + ST);
-  const f32x4* k2a = (const f32x4*)(st->ka_base + ST);
-  const int n_sums = phase == PH_P0 ? 4 : 2;
-  for (int j = 0; j < n_sums; ++j) {
-    const f32x4* pa;
-    const f32x4* pb = nullptr;
-    const f32x4* py;
-    if (phase == PH_P0) {
-      pa = j == 0 ? y : (j == 1 ? a : (j == 2 ? k1y : k1a));
-      py = (j & 1) ? a : y;
-    } else {
-      pa = j == 0 ? k2y : k2a;
-      pb = j == 0 ? k1y : k1a;
-      py = j == 0 ? y : a;
-    }
-    float s = 0.0f;
-    for (long long i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-      f32x4 d = pa[i];
-      const f32x4 yv = py[i];
-      if (pb) d -= pb[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float r = d[k] / (atol + fabsf(yv[k]) * rtol);
-        s += r * r;
-      }
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) parts[(size_t)j * part_stride + blockIdx.x] = sh[0];
-    __syncthreads();
-  }
 }
 
 __global__ void adj_init_kernel(AdjCtl* st, AdjCtl init) { *st = init; }
@@ -345,11 +311,10 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
   void* ws = workspace;
   const int NH = L.NH, NL = f->n_convs;
   const size_t st_b = (size_t)batch * L.C * kPix * 4;
-  const long long n4 = (long long)(st_b / 16);
   int rc;
 
   PersistScope persist;
-  if ((rc = persist.begin(f, f_dgrad, 2 + 11 + 12 + 62)) != ODEHIP_OK) return rc;
+  if ((rc = persist.begin(f, f_dgrad, 2 + 15 + 14 + 62)) != ODEHIP_OK) return rc;
   if (!persist.recording()) return ODEHIP_OK;   // no persistent walk on this device / switched off: the host loop takes the call
 
   if (!g_adj_mailbox) ODEHIP_CHECK_HIP(hipHostMalloc((void**)&g_adj_mailbox, sizeof(AdjMailbox), hipHostMallocCoherent));
@@ -418,6 +383,61 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
     n_rows += 2 * NL;
     return enqueue_dgrad_chain(f, f_dgrad, batch, gpv, hidv, a, stream);
   };
+  // The two halves of an augmented evaluation as ROWS handed back to the caller (captured with a private recorder) instead of
+  // appended: program P2 weaves the input-gradient chain of stage s with the forward chain of stage s + 1 (they are independent).
+  ConvArgs cap_buf[2 * ODEHIP_MAX_LAYERS];
+  auto capture = [&](std::vector<ConvArgs>& out, auto&& fn) -> int {
+    ConvRecorder tmp = {cap_buf, 0, 2 * ODEHIP_MAX_LAYERS};
+    ConvRecorder* const outer = g_conv_recorder;
+    g_conv_recorder = &tmp;
+    const int r = fn();
+    g_conv_recorder = outer;
+    out.assign(cap_buf, cap_buf + tmp.count);
+    return r;
+  };
+  auto rows_f = [&](int s, const float* Y, const CombineArgs& cy_, std::vector<ConvArgs>& out) -> int {
+    return capture(out, [&]() -> int {
+      float* hidv[ODEHIP_MAX_LAYERS];
+      for (int l = 0; l < NH; ++l) hidv[l] = s_hid(s, l);
+      return enqueue_f_saving(f, Y, batch, hidv, ping, pong, &cy_, nullptr, nullptr, stream);
+    });
+  };
+  auto rows_d = [&](int s, const CombineArgs& ca_, std::vector<ConvArgs>& out) -> int {
+    return capture(out, [&]() -> int {
+      float* hidv[ODEHIP_MAX_LAYERS];
+      for (int l = 0; l < NH; ++l) hidv[l] = s_hid(s, l);
+      float* gpv[ODEHIP_MAX_LAYERS];
+      for (int l = 0; l < NL; ++l) gpv[l] = s_gp(s, l);
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.combine = 1;
+      a.cmb = ca_;
+      return enqueue_dgrad_chain(f, f_dgrad, batch, gpv, hidv, a, stream);
+    });
+  };
+  auto emit = [&](ConvArgs a, int dep_back) -> int {
+    a.dep_back = dep_back;
+    ++n_rows;
+    return launch_conv(a, f->ks, stream);
+  };
+  // norm row: part(j) <- per-wave sums of ((a - b) / (atol + |y| rtol))^2
+  auto norm_row = [&](int j, const float* a_, const float* b_, const float* y_) -> int {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.combine = 5;
+    a.qout = L.C / 4;
+    a.batch = batch;
+    a.cmb.order = 1;
+    a.cmb.y = y_;
+    a.cmb.k_prev[0] = a_;
+    a.cmb.k_prev[1] = b_;
+    a.cmb.n_prev = b_ ? 2 : 1;
+    a.cmb.err_partials = L.part(ws, j);
+    a.cmb.rtol = rtol;
+    a.cmb.atol = atol;
+    ++n_rows;
+    return launch_conv(a, f->ks, stream);
+  };
   AdjCtl init;
   memset(&init, 0, sizeof(init));
   CombineArgs cy, ca;
@@ -442,6 +462,10 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
   ca.k_scale = 1.0f;
   ca.k_out = kaA;
   if ((rc = eval_aug(0, Ycur, cy, ca)) != ODEHIP_OK) return rc;
+  // _select_initial_step: d0 over (y, a), d1 over (k1_y, k1_a)
+  if ((rc = norm_row(0, Ycur, nullptr, Ycur)) != ODEHIP_OK || (rc = norm_row(1, Acur, nullptr, Acur)) != ODEHIP_OK ||
+      (rc = norm_row(2, kyA, nullptr, Ycur)) != ODEHIP_OK || (rc = norm_row(3, kaA, nullptr, Acur)) != ODEHIP_OK)
+    return rc;
   init.rows_p0[1] = n_rows - init.rows_p0[0];
   init.rows_p3p0[1] = n_rows - init.rows_p3p0[0];
   // -- P1: the Euler point y + h0 * k1 (stage 1 of the slot)
@@ -455,6 +479,8 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
     cy.k_out = ky[1];
     ca.k_out = ka[1];
     if ((rc = eval_aug(1, s_xin(1), cy, ca)) != ODEHIP_OK) return rc;
+    // d2 over (k(Euler point) - k1)
+    if ((rc = norm_row(0, ky[1], kyA, Ycur)) != ODEHIP_OK || (rc = norm_row(1, ka[1], kaA, Acur)) != ODEHIP_OK) return rc;
   }
   init.rows_p1[1] = n_rows - init.rows_p1[0];
   // -- P2: an attempted step
@@ -466,7 +492,8 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
     const float* k0a[1] = {kaA};
     if ((rc = ew(s_xin(1), Ycur, 1, k0y, &b21, hp, nullptr)) != ODEHIP_OK) return rc;
     if ((rc = ew(s_gp(1, NH), Acur, 1, k0a, &b21, hp, nullptr)) != ODEHIP_OK) return rc;
-    for (int s = 2; s <= 7; ++s) {  // stage s lives at index s-1 of the slot
+    std::vector<ConvArgs> F[7], D[7];   // rows of evaluation e = s - 1 (stage s lives at index s-1 of the slot)
+    for (int s = 2; s <= 7; ++s) {
       memset(&cy, 0, sizeof(cy));
       memset(&ca, 0, sizeof(ca));
       cy.order = ca.order = 1;
@@ -495,7 +522,32 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
         cy.rtol = ca.rtol = rtol;
         cy.atol = ca.atol = atol;
       }
-      if ((rc = eval_aug(s - 1, s_xin(s - 1), cy, ca)) != ODEHIP_OK) return rc;
+      if ((rc = rows_f(s - 1, s_xin(s - 1), cy, F[s - 1])) != ODEHIP_OK) return rc;
+      if ((rc = rows_d(s - 1, ca, D[s - 1])) != ODEHIP_OK) return rc;
+      ODEHIP_REQUIRE((int)F[s - 1].size() == NL && (int)D[s - 1].size() == NL, "adjoint: unexpected row count of an evaluation");
+    }
+    // Order: F1 | (F2, D1) woven | (F3, D2) | ... | (F6, D5) | D6.  Y_{s+1} needs only the forward chains up to stage s and A_{s+1}
+    // only the input-gradient chains, whose masks come from the SAME stage's forward chain: D_e and F_{e+1} are independent, so
+    // in a woven pair every row's predecessor in its own chain lies two rows back (dep_back = 1: its input is loaded and transformed
+    // while the consumers still multiply the other chain's row).
+    static const bool weave = [] { const char* e = getenv("ODEHIP_ADJOINT_WEAVE"); return !(e && e[0] == '0'); }();
+    if (weave) {
+      for (int j = 0; j < NL; ++j)
+        if ((rc = emit(F[1][j], 0)) != ODEHIP_OK) return rc;
+      for (int e = 1; e <= 5; ++e)
+        for (int j = 0; j < NL; ++j) {
+          if ((rc = emit(F[e + 1][j], (e == 1 && j == 0) ? 0 : 1)) != ODEHIP_OK) return rc;   // F2's first row follows F1's last
+          if ((rc = emit(D[e][j], 1)) != ODEHIP_OK) return rc;
+        }
+      for (int j = 0; j < NL; ++j)
+        if ((rc = emit(D[6][j], 0)) != ODEHIP_OK) return rc;
+    } else {
+      for (int e = 1; e <= 6; ++e) {
+        for (int j = 0; j < NL; ++j)
+          if ((rc = emit(F[e][j], 0)) != ODEHIP_OK) return rc;
+        for (int j = 0; j < NL; ++j)
+          if ((rc = emit(D[e][j], 0)) != ODEHIP_OK) return rc;
+      }
     }
   }
   init.rows_p2[1] = n_rows - init.rows_p2[0];
@@ -540,8 +592,6 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
     if (enq == 0) rc = persist.finish(nullptr, nullptr, nullptr, batch, psync, f->ks, stream, /*sync_is_zero=*/true);
     else rc = persist.relaunch(batch, psync, stream, /*sync_is_zero=*/true);
     if (rc != ODEHIP_OK) return rc;
-    hipLaunchKernelGGL(adj_norms_kernel, dim3(256), dim3(256), 0, stream, state, L.part(ws, 0), part_stride, n4);
-    ODEHIP_CHECK_HIP(hipGetLastError());
     ++enq;
     while (g_adj_mailbox->ticks + 1 < enq) {
       if (g_adj_mailbox->ticks != seen) {

@@ -413,6 +413,7 @@ int launch_conv(const ConvArgs& a_in, int ks, hipStream_t stream) {
     return ODEHIP_OK;
   }
   if (a_in.combine == 4) return launch_ew_row(a_in, stream);
+  ODEHIP_REQUIRE(a_in.combine != 5, "a norm row only exists inside the adaptive persistent walk");
   ConvArgs a = a_in;
   a.debug = g_debug_flags;
   a.dbg = g_debug_buf;

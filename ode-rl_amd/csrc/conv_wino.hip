@@ -62,6 +62,8 @@ struct PersistHook {
   bool split_wait;     // the input chunks 0/1 and 2/3 come from the two co tiles of a 64 -> 64 layer: wait for them separately
   int sleep6;          // solo: s_sleep(6) periods (0.18 us each) in front of the first poll
   const unsigned long long* reloc;  // adaptive walk: base addresses of the relocation classes (rel() below), or null
+  unsigned wait_target;  // what the partners' flags must have reached before this row's input is loaded (target, or target - 1
+                         // for a row that does not depend on the row in front of it: ConvArgs::dep_back)
 };
 
 // Relocatable pointers of the adaptive walk's tables.  A driver whose buffers are chosen ON THE DEVICE (the slot an adaptive
@@ -97,7 +99,7 @@ __device__ __forceinline__ void wait_done(const PersistHook& hk, int sel_mask = 
   int n = 0;
   const int lane = threadIdx.x & 63;
   const bool mine = lane < 16 && (lane & sel_mask) == sel_val;
-  while (!__all(!mine || __hip_atomic_load(hk.done + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
+  while (!__all(!mine || __hip_atomic_load(hk.done + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.wait_target)) {
     __builtin_amdgcn_s_sleep(1);
     if ((++n & 1023) == 0) {
       if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hk.abort_tag) break;
@@ -235,7 +237,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
         // dopri5 forward 0: 0.799, 4: 0.783, 5: 0.777, 8: 0.796; 128-channel-ended stack 0: 1.640, 4: 1.627, 5: 1.638.  A barrier that
         // releases the producers exactly when the consumers' last MFMA has issued is worse than the fixed sleep (it also holds back
         // the next layer's first weight chunk).
-        if (hk.solo)
+        if (hk.solo && hk.wait_target == hk.target)   // (a row with a relaxed dependency has nothing to sleep for)
           for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
         if (hk.split_wait) wait_done(hk, 0x8, 0x0); else wait_done(hk);
       }
@@ -377,15 +379,28 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
         }
       }
       if (d_has_y) {
-        for (int j = 0; j < np; ++j) {   // the sums over the earlier stages, in the order of combine1_prev (conv_common.h)
-          const float* kp = rel(rl, m.k_prev[j]);
-          const float cA = m.c1[j], cB = d_err ? m.ce[j] : m.c2[j];
+        // the sums over the earlier stages, in the order of combine1_prev (conv_common.h).  Fully unrolled with the operands of all
+        // stages fetched up front: as a run-time loop every iteration waited for its own scalar loads (pointer, relocation base,
+        // coefficients) and then for its vector loads -- ~1.2 us per earlier stage in front of the layer's first barrier
+        // (tools/adjoint_stamps.py: the consumers of a stage-7 layer arrived 2.9 us after their producers were ready)
+        const float* kp[ODEHIP_MAX_STAGES - 1];
+        float cA[ODEHIP_MAX_STAGES - 1], cB[ODEHIP_MAX_STAGES - 1];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
-            const f32x4 kv = *(const f32x4*)(kp + off);
-            d_sa[q] = fma4(kv, cA, d_sa[q]);
-            if (needB) d_sb[q] = fma4(kv, cB, d_sb[q]);
+        for (int j = 0; j < ODEHIP_MAX_STAGES - 1; ++j) {
+          kp[j] = j < np ? rel(rl, m.k_prev[j]) : nullptr;
+          cA[j] = m.c1[j];
+          cB[j] = d_err ? m.ce[j] : m.c2[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ODEHIP_MAX_STAGES - 1; ++j) {
+          if (j < np) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const size_t off = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+              const f32x4 kv = *(const f32x4*)(kp[j] + off);
+              d_sa[q] = fma4(kv, cA[j], d_sa[q]);
+              if (needB) d_sb[q] = fma4(kv, cB[j], d_sb[q]);
+            }
           }
         }
       }
@@ -634,7 +649,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const float* __res
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);
   const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
-  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true, 0, nullptr};
+  const PersistHook none = {nullptr, 0u, 0, nullptr, nullptr, false, nullptr, nullptr, 0, 0u, true, false, true, true, 0, nullptr, 0u};
   wino_layer<NCHUNK, DBG, false>(p_src, p_u, p_qin, a, b, ct, rh, smem, none);
 }
 
@@ -682,6 +697,33 @@ __device__ __forceinline__ void ew_row(const ConvArgs& a, int b, int ct, int rh,
   const int ch = wave >> 1, thh = wave & 1, i16 = lane & 15, kq = lane >> 4;
   const int Q = ct * 8 + ch * 4 + kq, tile = thh * 16 + i16, oty = tile >> 3, otx = tile & 7, r0 = rh * 8;
   const float* const yp = rel(rl, m.y);
+  if (a.combine == 5) {
+    // norm row: this wave's share of sum(((a - b) / (atol + |y| * rtol))^2), a = k_prev[0], b = k_prev[1] (n_prev == 2), into
+    // err_partials[(sample * 4 + workgroup of the sample) * 4 + wave] -- the scaled sums of squares of an initial-step search
+    // (torchdiffeq _select_initial_step) without a separate reduction launch; the controller adds the partials in a fixed order
+    const float* const pa = rel(rl, m.k_prev[0]);
+    const float* const pb = m.n_prev > 1 ? rel(rl, m.k_prev[1]) : nullptr;
+    float sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t o = (((size_t)b * QOUT + Q) * kPix + (r0 + 2 * oty + (q >> 1)) * 16 + 2 * otx + (q & 1)) * 4;
+      f32x4 d = *(const f32x4*)(pa + o);
+      const f32x4 yv = *(const f32x4*)(yp + o);
+      if (pb) d -= *(const f32x4*)(pb + o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = d[i] / __builtin_fmaf(fabsf(yv[i]), m.rtol, m.atol);
+        sum = __builtin_fmaf(r, r, sum);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) m.err_partials[(b * 4 + ct * 2 + rh) * 4 + wave] = sum;
+    wait_vmcnt<0>();
+    if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(hk.done + hk.word0 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   float* const o1 = rel(rl, m.out1);
   float* const o2 = rel(rl, m.out2);
   f32x4 s1[4], s2[4];
@@ -785,9 +827,10 @@ __device__ __forceinline__ void persist_walk(const PersistArgs& pa, const ConvAr
         const PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                                 pa.out_nchw, (pa.stamps && lid == 0 && bs == group && l < 64) ? pa.stamps + l * 8 : nullptr, pa.batch,
                                 pa.epoch + 1u, l == 0, n_interleaved == 1, true, true, pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0),
-                                ADAPT ? pa.reloc : nullptr};
+                                ADAPT ? pa.reloc : nullptr,
+                                (pa.epoch << 10) + (unsigned)(ADAPT && a.dep_back > 0 && l > 0 ? l - 1 : l)};
         if constexpr (ADAPT) {
-          if (a.combine == 4) ew_row<16>(a, bs, ct, rh, hk);
+          if (a.combine >= 4) ew_row<16>(a, bs, ct, rh, hk);
           else wino_layer<4, false, true, 16, true>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
         } else {
           wino_layer<4, false, true>(uniform_ptr(src), uniform_ptr(u), 16, a, bs, ct, rh, smem, hk);
@@ -859,7 +902,7 @@ __device__ __forceinline__ void persist_walk_v(const PersistArgs& pa, const Conv
         const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
         PersistHook hk = {pa.done + (size_t)bs * kDoneStride, (pa.epoch << 10) + (unsigned)l, (lid & 3) * 4, pa.xcc_of + nwg, pa.host_err, fence,
                           pa.out_nchw, nullptr, pa.batch, pa.epoch + 1u, l == 0, n_interleaved == 1, true, false,
-                          pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0), nullptr};
+                          pa.sleep6 + (prev_combine == 1 ? pa.sleep6_combine : 0), nullptr, (pa.epoch << 10) + (unsigned)l};
         if (qout == 16) {
           if (qin == 16) wino_layer<4, false, true, 16>(src, u, 16, a, bs, ct, rh, smem, hk);
           else           wino_layer<8, false, true, 16>(src, u, 32, a, bs, ct, rh, smem, hk);

@@ -100,9 +100,14 @@ struct ConvArgs {
   int qout;    // output quads (cout / 4)
   int batch;
   int relu;
-  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue; 2/3: BwdArgs epilogues; 4: elementwise row (no conv; see above)
+  int combine; // 0: plain store (+relu); 1: CombineArgs epilogue; 2/3: BwdArgs epilogues; 4: elementwise row (no conv; see above);
+               // 5: norm row (adaptive walk only): err_partials <- per-wave sums of ((k_prev[0] - k_prev[1]) / (atol + |y| rtol))^2
   int debug;   // diagnostic ablation bits (tools/conv_microbench.py): 1 skip DMA, 2 skip MFMA, 4 skip epilogue
   int h_by_value;  // persistent tables of fixed-grid drivers: cmb.atol holds the step size itself (read instead of *h_ptr)
+  int dep_back;    // adaptive walk: 1 = this row does NOT depend on the row right in front of it (two independent chains woven into
+                   // one table, e.g. the input-gradient chain of a stage and the forward chain of the next): its producers only wait
+                   // for the row before that, i.e. they load and transform its input while the consumers still multiply the other
+                   // chain's row -- the partner hand-off leaves the critical path
   const int* skip;          // if non-null and *skip != 0 the kernel does nothing (adaptive solver already done)
   unsigned long long* dbg;  // debug & 8: per-workgroup stamps (8 x u64 per workgroup)
   CombineArgs cmb;

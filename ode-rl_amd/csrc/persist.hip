@@ -65,7 +65,7 @@ static bool persist_available() {
 // 3: a row only the ADAPTIVE walk takes (wino_persist_d_kernel): an elementwise row, or a 64 -> 64 layer whose stage combine is
 //    written in order 1 (the adaptive solver's drivers)
 static int persist_layer_kind(const ConvArgs& a) {
-  if (a.combine == 4) return a.qout == 16 && !a.src2 ? 3 : 0;
+  if (a.combine == 4 || a.combine == 5) return a.qout == 16 && !a.src2 ? 3 : 0;   // elementwise / norm rows
   if (!a.w_wino || a.w_bf16 || a.src2 || a.q1 != a.qin || a.combine < 0 || a.combine > 3) return 0;
   if (a.qin == 16 && a.qout == 16) return (a.combine == 1 && a.cmb.order == 1) ? 3 : 1;
   if ((a.qin == 32 && a.qout == 16) || (a.qin == 16 && a.qout == 32)) return 2;
