@@ -3,6 +3,6 @@
 A=$1; B=$2; R=${3:-3}
 for i in $(seq $R); do
   for L in $A $B; do
-    ODEHIP_LIB=$L python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_us'],3))"
+    ODEHIP_LIB=$L python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-model 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$L', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_us'],3))"
   done
 done

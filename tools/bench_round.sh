@@ -16,18 +16,18 @@ except Exception as e:
 PY
 }
 run config1_headline
-run config0_b4 --batch 4 --no-config0 --no-cpu-baseline
-run config1_train --train --no-cpu-baseline
-run dopri5_fwd --method dopri5 --no-cpu-baseline --no-config0
-run dopri5_train --method dopri5 --train --no-cpu-baseline
-run config2_adjoint --method dopri5 --train --adjoint --rtol 1e-5 --atol 1e-6 --no-cpu-baseline --steps 20
-run config3_vidode_fwd --shape V --no-cpu-baseline --no-config0
-run config3_vidode_train --shape V --train --no-cpu-baseline
-run config4_bf16_fwd --dtype bf16 --batch 128 --frames 40 --no-cpu-baseline --no-config0 --steps 20
-run config4_bf16_train --dtype bf16 --batch 128 --frames 40 --train --no-cpu-baseline --steps 10
-run bf16_b64_t10_fwd --dtype bf16 --no-cpu-baseline --no-config0
-run bf16_b64_t10_train --dtype bf16 --train --no-cpu-baseline
-run f32_b128_t40_fwd --batch 128 --frames 40 --no-cpu-baseline --no-config0 --steps 10 --no-train-leg
-ODEHIP_PERSISTENT=0 run config1_per_layer --no-cpu-baseline --no-config0 --no-train-leg
-ODEHIP_BENCH_REHEARSAL=1 run rehearsal_2ranks_one_gpu --gpus 2 --steps 10 --no-cpu-baseline
+run config0_b4 --batch 4 --no-config0 --no-cpu-baseline --no-model
+run config1_train --train --no-cpu-baseline --no-model
+run dopri5_fwd --method dopri5 --no-cpu-baseline --no-config0 --no-model
+run dopri5_train --method dopri5 --train --no-cpu-baseline --no-model
+run config2_adjoint --method dopri5 --train --adjoint --rtol 1e-5 --atol 1e-6 --no-cpu-baseline --steps 20 --no-model
+run config3_vidode_fwd --shape V --no-cpu-baseline --no-config0 --no-model
+run config3_vidode_train --shape V --train --no-cpu-baseline --no-model
+run config4_bf16_fwd --dtype bf16 --batch 128 --frames 40 --no-cpu-baseline --no-config0 --steps 20 --no-model
+run config4_bf16_train --dtype bf16 --batch 128 --frames 40 --train --no-cpu-baseline --steps 10 --no-model
+run bf16_b64_t10_fwd --dtype bf16 --no-cpu-baseline --no-config0 --no-model
+run bf16_b64_t10_train --dtype bf16 --train --no-cpu-baseline --no-model
+run f32_b128_t40_fwd --batch 128 --frames 40 --no-cpu-baseline --no-config0 --steps 10 --no-train-leg --no-model
+ODEHIP_PERSISTENT=0 run config1_per_layer --no-cpu-baseline --no-config0 --no-train-leg --no-model
+ODEHIP_BENCH_REHEARSAL=1 run rehearsal_2ranks_one_gpu --gpus 2 --steps 10 --no-cpu-baseline --no-model
 echo bench_round done
