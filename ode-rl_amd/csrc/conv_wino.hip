@@ -1020,6 +1020,342 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
   return ODEHIP_OK;
 }
 
+
+// ================================================================================================================================
+// Small batches (B <= 16; the reference trains at batch 4, configs.yaml:7): SIXTEEN workgroups per sample.
+// The walk above gives a sample four workgroups; at B = 4 that is 16 of 256 CUs, and a layer still costs its full 7.3 us because
+// a consumer wave multiplies a whole (16 co x 16 tiles) block for all 16 transform positions (5.2 us).  Here workgroup
+// (sample, 16-channel tile cq, row quarter rq) owns ONE such block and its four consumer waves split the positions by COLUMN of
+// the 4x4 transform (wave w: xi = w, 4 + w, 8 + w, 12 + w): 16 MFMAs per 16-channel chunk and wave instead of 64.  The first half of
+// the output transform (over the rows of M, S_a[col] -- the expressions of the 4-workgroup kernel) is wave-local; the second half
+// needs all four columns, so the waves exchange S through LDS (8 KiB) and wave (a, b) finishes output pixel (a, b) of every 2x2 tile
+// in the 4-workgroup kernel's order of operations: results are BIT-IDENTICAL to the other walk.  Producers: each wave DMAs and
+// transforms the channel quad it loaded, one V row per lane (64 lanes = 16 tiles x 4 rows).  Hand-off: the sample's flag line has
+// 64 words (16 workgroups x 4 consumer waves); a workgroup waits for the twelve workgroups of row quarters rq-1 .. rq+1 (all channels
+// of the input rows it reads).  Forward tables only (plain / ReLU stores and the prefetched stage combine); LDS 88 KiB.
+constexpr int k16U = 16 * 1024;    // U chunk: 16 xi x [quad 4][co 16][4 ci]
+constexpr int k16Raw = 8 * 1024;   // raw chunk: 4 quads x 2 KiB: 6 rows x 20 slots of 16 B
+constexpr int k16V = 16 * 1024;    // V chunk: 16 xi x [quad 4][tile 16][4 ci]
+constexpr int k16X = 8 * 1024;     // exchange: [a 2][col 4][lane 64] quads
+constexpr int kWino16Lds = 2 * k16U + 2 * k16Raw + 2 * k16V + k16X;
+
+struct Hook16 {
+  unsigned* done;      // the sample's 64 flag words
+  unsigned target;     // index of this layer
+  unsigned* abort_;
+  unsigned* host_err;
+  bool fence, first;
+  float* nchw_base;
+  int sleep6;
+};
+
+__device__ __forceinline__ void wait_done16(const Hook16& hk, int lo_word, int hi_word) {
+  int n = 0;
+  const int lane = threadIdx.x & 63;
+  const bool mine = lane >= lo_word && lane < hi_word;
+  while (!__all(!mine || __hip_atomic_load(hk.done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++n & 1023) == 0) {
+      if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) break;
+      if (n > (1 << 23)) {
+        __hip_atomic_store(hk.abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *hk.host_err = 3;
+        break;
+      }
+    }
+  }
+  if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, const float* __restrict__ p_u, const ConvArgs& a, int b,
+                                             int cq, int rq, char* smem, const Hook16& hk) {
+  char* const Ub = smem;
+  char* const Rb = smem + 2 * k16U;
+  char* const Vb = smem + 2 * k16U + 2 * k16Raw;
+  char* const Xb = smem + 2 * k16U + 2 * k16Raw + 2 * k16V;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = rq * 4;
+  constexpr int nchunk = 4;
+
+  if (wave >= 4) {
+    // =========================================== PRODUCERS ===========================================
+    const int pw = wave - 4;
+    const int ct = cq >> 1, half = cq & 1;
+    const unsigned u_tile_bytes = (unsigned)nchunk * kWU;   // the 32-channel tile this 16-channel tile is half of
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc((const char*)p_u + (size_t)ct * u_tile_bytes, u_tile_bytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p_src + (size_t)b * 16 * kQuadBytes, 16u * kQuadBytes);
+    int vr[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int s = 64 * p + lane;
+      const int row = s / 20, w = s - row * 20;
+      const int pc = w < 9 ? 2 * w : 2 * (w - 9) + 1;
+      const int irow = r0 - 1 + row, col = pc - 1;
+      vr[p] = (s < 120 && w < 18 && irow >= 0 && irow < kHW && col >= 0 && col < kHW) ? irow * 256 + col * 16 : kOobOffset;
+    }
+    // U: the chunk's 64 (xi, quad) pieces of this channel half are 256 B each, 512 B apart: one instruction moves four of them
+    const int vu = (lane >> 4) * 512 + half * 256 + (lane & 15) * 16;
+    auto issue_u = [&](int c, int buf) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int p = pw * 4 + g;   // pieces 4p .. 4p + 3
+        dma16(ru, Ub + buf * k16U + p * 1024, vu, c * kWU + p * 2048);
+      }
+    };
+    auto issue_raw = [&](int c, int buf) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, ODEHIP_LDS_PTR(Rb + buf * k16Raw + pw * 2048 + p * 1024), 16, vr[p],
+                                                 (c * 4 + pw) * kQuadBytes, 0, 16);
+    };
+    // transform: lane = (tile tt, V row vi); this wave's quad tq = pw
+    const int tt = lane & 15, vi = lane >> 4, tq = pw;
+    const int tty = tt >> 3, ttx = tt & 7;
+    // V row vi of B^T d:  0: p0 - p2   1: p1 + p2   2: p2 - p1   3: p3 - p1  (sign of row 3 folded into U): T = a + sg * b
+    const int ra = vi == 0 ? 0 : (vi == 1 ? 1 : (vi == 2 ? 2 : 3));
+    const int rb = vi == 0 ? 2 : (vi == 1 ? 2 : 1);
+    const float sg = vi == 1 ? 1.0f : -1.0f;
+    const int raw_base = tq * 2048 + (2 * tty * 20 + ttx) * 16;
+    const int off_a = raw_base + ra * 320, off_b = raw_base + rb * 320;
+    const int v_off = tq * 256 + tt * 16;
+    auto transform = [&](int rbuf, int vbuf) {
+      const char* r = Rb + rbuf * k16Raw;
+      f32x4 T[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cj = ((j & 1) * 9 + (j >> 1)) * 16;
+        const f32x4 da = *(const f32x4*)(r + off_a + cj);
+        const f32x4 db = *(const f32x4*)(r + off_b + cj);
+        T[j] = da + db * sg;
+      }
+      char* v = Vb + vbuf * k16V + v_off + vi * 4 * 1024;
+      *(f32x4*)(v + 0 * 1024) = pk_sub(T[0], T[2]);
+      *(f32x4*)(v + 1 * 1024) = T[1] + T[2];
+      *(f32x4*)(v + 2 * 1024) = pk_sub(T[2], T[1]);
+      *(f32x4*)(v + 3 * 1024) = pk_sub(T[1], T[3]);
+    };
+    // DMA order per wave: U_0 (4) | raw_0 (2) | raw_1 (2) | then per iteration c: U_{c+1} (4) | raw_{c+2} (2)
+    issue_u(0, 0);
+    if (!hk.first) {
+      for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
+      const int lo = rq > 0 ? (rq - 1) * 16 : 0, hi = rq < 3 ? (rq + 2) * 16 : 64;
+      wait_done16(hk, lo, hi);
+    }
+    issue_raw(0, 0);
+    issue_raw(1, 1);
+    wait_vmcnt<2>();   // U_0 and raw_0 landed
+    transform(0, 0);
+#pragma unroll
+    for (int c = 0; c < nchunk; ++c) {
+      __builtin_amdgcn_s_barrier();  // [c]
+      if (c + 1 < nchunk) {
+        issue_u(c + 1, (c + 1) & 1);
+        if (c + 2 < nchunk) {
+          issue_raw(c + 2, c & 1);
+          wait_vmcnt<6>();           // raw_{c+1} landed
+        } else {
+          wait_vmcnt<4>();
+        }
+        transform((c + 1) & 1, (c + 1) & 1);
+        if (c + 2 < nchunk) wait_vmcnt<2>(); else wait_vmcnt<0>();  // U_{c+1} landed
+      }
+    }
+    __builtin_amdgcn_s_barrier();    // [X] the consumers' exchange
+    return;
+  }
+
+  // ============================================= CONSUMERS =============================================
+  const int i16 = lane & 15, kq = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_off = kq * 256 + i16 * 16;       // same offset in a U and in a V position block
+  const int Q = cq * 4 + kq;
+  const int oa = wave >> 1, ob = wave & 1;        // the output pixel of every 2x2 tile this wave finishes
+  const int oty = i16 >> 3, otx = i16 & 7;
+  const int P = (r0 + 2 * oty + oa) * 16 + 2 * otx + ob;
+  const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *(const f32x4*)(a.bias + Q * 4);
+  // epilogue operands fetched now (this lane's own earlier outputs, as in the 4-workgroup walk)
+  const int e_combine = a.combine;
+  const int e_relu = a.relu;
+  float* const e_dst = a.dst;
+  int e_np = 0;
+  float* e_kout = nullptr;
+  float* e_out1 = nullptr;
+  float* e_out2 = nullptr;
+  float* e_nchw = nullptr;
+  bool e_y = false;
+  float e_h = 1.0f, e_ks = 1.0f, e_c1c = 0.0f, e_c2c = 0.0f, e_c1[3] = {0.f, 0.f, 0.f}, e_c2[3] = {0.f, 0.f, 0.f};
+  f32x4 e_yv = {0.f, 0.f, 0.f, 0.f}, e_kv[3];
+  if (e_combine == 1) {
+    const CombineArgs& m = a.cmb;
+    e_np = m.n_prev;
+    e_h = m.atol;   // the step size by value (persistent tables of the fixed-grid drivers)
+    e_ks = m.k_scale;
+    e_c1c = m.c1[e_np];
+    e_c2c = m.c2[e_np];
+    e_kout = m.k_out;
+    e_out1 = m.out1;
+    e_out2 = m.out2;
+    e_nchw = a.dbg ? hk.nchw_base + ((size_t)a.dbg - 1) : nullptr;
+    e_y = m.y != nullptr;
+    if (e_y) e_yv = *(const f32x4*)(m.y + off);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j < e_np) e_kv[j] = *(const f32x4*)(m.k_prev[j] + off);
+      e_c1[j] = m.c1[j];
+      e_c2[j] = m.c2[j];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < nchunk; ++c) {
+    __builtin_amdgcn_s_barrier();  // [c]
+    const char* u = Ub + (c & 1) * k16U + frag_off;
+    const char* v = Vb + (c & 1) * k16V + frag_off;
+    f32x4 wf[4], xf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wf[i] = *(const f32x4*)(u + (4 * i + wave) * 1024);
+      xf[i] = *(const f32x4*)(v + (4 * i + wave) * 1024);
+    }
+    // per position the chunk's four K-steps in the 4-workgroup kernel's order (.x .y .z .w); the four positions interleaved
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, xf[i].x, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, xf[i].y, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].z, xf[i].z, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].w, xf[i].w, acc[i], 0, 0, 0);
+  }
+  // first half of the output transform, over the rows of M (this wave's column): the 4-workgroup kernel's S[0][col], S[1][col]
+  {
+    const f32x4 S0 = acc[0] + acc[1] + acc[2];
+    const f32x4 S1 = pk_sub(pk_sub(acc[1], acc[2]), acc[3]);
+    *(f32x4*)(Xb + (0 * 4 + wave) * 1024 + lane * 16) = S0;
+    *(f32x4*)(Xb + (1 * 4 + wave) * 1024 + lane * 16) = S1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();    // [X]
+  f32x4 val;
+  {
+    const char* x = Xb + oa * 4 * 1024 + lane * 16;
+    if (ob == 0) {
+      val = *(const f32x4*)(x) + *(const f32x4*)(x + 1024) + *(const f32x4*)(x + 2048) + bias4;
+    } else {
+      val = pk_sub(pk_sub(*(const f32x4*)(x + 1024) + bias4, *(const f32x4*)(x + 2048)), *(const f32x4*)(x + 3072));
+    }
+  }
+  if (!e_combine) {
+    if (e_relu) {
+      val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
+    }
+    *(f32x4*)(e_dst + off) = val;
+  } else {
+    const f32x4 kc = val * e_ks;
+    if (e_kout) *(f32x4*)(e_kout + off) = kc;
+    if (e_y) {
+      if (e_out1) {
+        f32x4 sa = kc * e_c1c;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) sa += e_kv[j] * e_c1[j];
+        *(f32x4*)(e_out1 + off) = e_yv + sa * e_h;
+      }
+      if (e_out2 || e_nchw) {
+        f32x4 sb = kc * e_c2c;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) sb += e_kv[j] * e_c2[j];
+        const f32x4 o2 = e_yv + sb * e_h;
+        if (e_out2) *(f32x4*)(e_out2 + off) = o2;
+        if (e_nchw) {
+          float* o = e_nchw + ((size_t)b * 64 + Q * 4) * kPix + P;
+          o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+        }
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(hk.done + (rq * 4 + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // 256 workgroups, dealt round-robin over the 8 XCDs: XCD x holds logical ids 32 x .. 32 x + 31 = two samples' sixteen workgroups
+  // each; sample s lives on XCD s % 8 (batches up to 8 get an XCD -- and its L2 -- per sample)
+  const int lid = ((int)blockIdx.x & 7) * 32 + ((int)blockIdx.x >> 3);
+  const int xcd = lid >> 5, slot = (lid >> 4) & 1, wg = lid & 15;
+  const int b = slot * 8 + xcd;
+  const int rq = wg >> 2, cq = wg & 3;
+  if (b >= pa.batch) return;
+  const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;
+  if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool fence = false;
+  for (int p = 0; p < 16; ++p) {
+    unsigned v = 0;
+    int n = 0;
+    while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~15) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++n > (1 << 23)) {
+        __hip_atomic_store(pa.xcc_of + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *pa.host_err = 2;
+        break;
+      }
+    }
+    fence |= (v != my_xcc);
+  }
+  fence = __builtin_amdgcn_readfirstlane(fence);
+  const ConvArgs* table = pa.table;
+  const float* src = table[0].src1;
+  const float* u = table[0].w_wino;
+  for (int l = 0; l < pa.n_layers; ++l) {
+    typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
+    const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
+    const float* src_next = src;
+    const float* u_next = u;
+    if (l + 1 < pa.n_layers) {
+      src_next = table[l + 1].src1;
+      u_next = table[l + 1].w_wino;
+      if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
+        const unsigned v = __builtin_nontemporal_load((const unsigned*)&table[l + 1] + threadIdx.x * 16);
+        asm volatile("" ::"v"(v));
+      }
+    }
+    const Hook16 hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6};
+    wino_layer16(uniform_ptr(src), uniform_ptr(u), a, b, cq, rq, smem, hk);
+    src = src_next;
+    u = u_next;
+  }
+}
+
+int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
+                          float* out_nchw, hipStream_t stream) {
+  static bool attr_set = false;
+  ODEHIP_REQUIRE(batch >= 1 && batch <= 16, "wino_persist16: batch %d out of range", batch);
+  if (!attr_set) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int per_cu = 0;
+    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist16_kernel, 512, kWino16Lds));
+    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist16: the kernel does not fit a CU");
+    attr_set = true;
+  }
+  PersistArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
+  pa.out_nchw = out_nchw;
+  static const int sleep6 = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : 0; }();
+  pa.sleep6 = sleep6;
+  hipLaunchKernelGGL(wino_persist16_kernel, dim3(256), dim3(512), kWino16Lds, stream, pa);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
 // returns 1 if the shape has no Winograd instantiation (the caller then runs the direct kernel)
 int launch_wino(const ConvArgs& a, hipStream_t stream) {
   switch (a.qin / 4) {

@@ -129,7 +129,10 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
                         bool adaptive = false, const int* n_layers_ptr = nullptr,           // adaptive: wino_persist_d_kernel (order-1
                         const unsigned long long* reloc = nullptr);                         // combines, elementwise rows, h on the device;
                                                                                             // {row0, rows} and relocation bases on the device)
-int launch_ew_row(const ConvArgs& a, hipStream_t stream);   // an elementwise row (combine == 4) as an ordinary launch
+int launch_ew_row(const ConvArgs& a, hipStream_t stream);
+// forward tables of a 64-channel stack at batch <= 16: sixteen workgroups per sample (conv_wino.hip, wino_persist16_kernel)
+int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
+                          float* out_nchw, hipStream_t stream);   // an elementwise row (combine == 4) as an ordinary launch
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_wino5(const ConvArgs& a, hipStream_t stream);  // 5x5 layers with a.w_wino (conv_wino5.hip); 1 = no such form, run the direct kernel
 int launch_bf16(const ConvArgs& a, hipStream_t stream);

@@ -349,8 +349,21 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
       table = volatile_ ? persist_table_async(rec_.items, rec_.count, stream) : persist_table(rec_.items, rec_.count, stream);
     }
     int rc;
+    // batches up to 16: forward tables of a 64-channel stack take the sixteen-workgroups-per-sample walk (a layer's matrix work is
+    // split four times finer; bit-identical results)
+    bool small16 = false;
+    if (table && !wide && !adaptive && batch <= 16 && hbuf && !rows_dev_ && !reloc_dev_) {
+      static const bool on16 = [] { const char* e = getenv("ODEHIP_PERSIST16"); return !(e && e[0] == '0'); }();
+      small16 = on16;
+      for (int i = 0; i < rec_.count && small16; ++i) {
+        const ConvArgs& a = rec_.items[i];
+        small16 = a.qin == 16 && a.qout == 16 && (a.combine == 0 || (a.combine == 1 && a.h_by_value && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order));
+      }
+    }
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
+      if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream);
+      else
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
                                kPersistGrid, stream, wide, adaptive, rows_dev_, reloc_dev_);
       if (volatile_) persist_table_async_done(stream);

@@ -190,3 +190,38 @@ def test_max_num_steps_counts_per_output_time(cuda):
             torchdiffeq_ref.odeint(_oracle_f(sd), z0, t, options={"max_num_steps": worst - 1}, **kw)
         again = ode_rl_amd.odeint(fd, z0.to(cuda), t, **kw)          # the failed call leaves the library usable
     assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("method", ["rk4", "midpoint", "euler"])
+@pytest.mark.parametrize("batch", [1, 3, 4, 8, 9, 16])
+def test_small_batch_walk_is_bit_identical_to_one_launch_per_layer(cuda, method, batch):
+    """Round 3: batches up to 16 (the reference trains at 4, configs.yaml:7) walk a forward trajectory with SIXTEEN workgroups per
+    sample (wino_persist16_kernel: the transform positions of a block split over the consumer waves, the output transform finished
+    through LDS in the 4-workgroup kernel's order of operations).  Bit-identical to one launch per layer, for every slot of the
+    sample -> XCD mapping (1 .. 16 samples), with and without result frames in the last stage; B = 17 takes the other walk."""
+    import ode_rl_amd
+    if not _persistent_on():
+        pytest.skip("persistent path switched off for this run")
+    lib = ode_rl_amd._lib.load()
+    torch.manual_seed(5)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    with torch.no_grad():
+        for p in f.parameters():
+            if p.dim() == 4:
+                p.mul_(2.0)
+    f = f.to(cuda)
+    z0 = (torch.randn(batch, 64, 16, 16, generator=torch.Generator().manual_seed(batch)) * 0.5).to(cuda)
+    t = torch.tensor([0.0, 0.2, 0.25, 0.6, 1.0], dtype=torch.float64)
+    with torch.no_grad():
+        p0 = lib.odehip_persistent_trajectory_launches()
+        sol = ode_rl_amd.odeint(f, z0, t, method=method)
+        assert lib.odehip_persistent_trajectory_launches() - p0 == 1
+        was = lib.odehip_set_persistent_trajectory(0)
+        try:
+            ref = ode_rl_amd.odeint(f, z0, t, method=method)
+        finally:
+            lib.odehip_set_persistent_trajectory(was)
+        again = ode_rl_amd.odeint(f, z0, t, method=method)
+    assert torch.isfinite(sol).all() and float((sol[-1] - sol[0]).norm() / sol[0].norm()) > 0.05
+    assert torch.equal(sol, ref)
+    assert torch.equal(again, sol)
