@@ -1032,7 +1032,8 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
 // in the 4-workgroup kernel's order of operations: results are BIT-IDENTICAL to the other walk.  Producers: each wave DMAs and
 // transforms the channel quad it loaded, one V row per lane (64 lanes = 16 tiles x 4 rows).  Hand-off: the sample's flag line has
 // 64 words (16 workgroups x 4 consumer waves); a workgroup waits for the twelve workgroups of row quarters rq-1 .. rq+1 (all channels
-// of the input rows it reads).  Forward tables only (plain / ReLU stores and the prefetched stage combine); LDS 88 KiB.
+// of the input rows it reads).  Forward tables (plain / ReLU stores, the prefetched stage combine) and reverse sweeps (mask layers
+// prefetched, targets through the shared epilogue); LDS 88 KiB.
 constexpr int k16U = 16 * 1024;    // U chunk: 16 xi x [quad 4][co 16][4 ci]
 constexpr int k16Raw = 8 * 1024;   // raw chunk: 4 quads x 2 KiB: 6 rows x 20 slots of 16 B
 constexpr int k16V = 16 * 1024;    // V chunk: 16 xi x [quad 4][tile 16][4 ci]
@@ -1210,6 +1211,13 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
       e_c1[j] = m.c1[j];
       e_c2[j] = m.c2[j];
     }
+  } else if (e_combine == 2) {   // ReLU-mask layer of a reverse sweep: the mask value is fetched now
+    const BwdArgs& w = a.bwd;
+    typedef const __attribute__((address_space(4))) float ConstF;
+    const float hb = a.h_by_value ? a.cmb.atol : (w.h_ptr ? *(ConstF*)w.h_ptr : 0.0f);
+    e_ks = w.sc_c + w.sc_h * hb;
+    e_y = w.mask_src != nullptr;
+    if (e_y) e_yv = *(const f32x4*)(w.mask_src + off);
   }
 #pragma unroll
   for (int c = 0; c < nchunk; ++c) {
@@ -1255,6 +1263,16 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
       val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
     }
     *(f32x4*)(e_dst + off) = val;
+  } else if (e_combine == 2) {
+    val *= e_ks;
+    if (e_y) {
+      val.x = e_yv.x > 0.0f ? val.x : 0.0f; val.y = e_yv.y > 0.0f ? val.y : 0.0f;
+      val.z = e_yv.z > 0.0f ? val.z : 0.0f; val.w = e_yv.w > 0.0f ? val.w : 0.0f;
+    }
+    *(f32x4*)(e_dst + off) = val;
+  } else if (e_combine == 3) {   // reverse-sweep targets: the shared epilogue, read from the table
+    float esum = 0.0f;
+    emit_quad<false>(a, b, Q, P, val, esum);
   } else {
     const f32x4 kc = val * e_ks;
     if (e_kout) *(f32x4*)(e_kout + off) = kc;
@@ -1349,8 +1367,11 @@ int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, un
   memset(&pa, 0, sizeof(pa));
   pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
   pa.out_nchw = out_nchw;
-  static const int sleep6 = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : 0; }();
-  pa.sleep6 = sleep6;
+  // Periods of 0.18 us the producers sleep in front of their first poll (a polling wave takes issue slots from the consumer wave of
+  // its SIMD).  Sweep, forward trajectory B = 4, T = 10, rk4 (ms): 0: 1.07, 1: 0.90, 2: 0.66, 3: 0.605, 4: 0.596, 6: 0.619; B = 12 / 16:
+  // 3: 0.88 / 0.80, 4: 0.621 / 0.620, 5: 0.608 / 0.617.
+  static const int sleep_env = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : -1; }();
+  pa.sleep6 = sleep_env >= 0 ? sleep_env : (batch > 8 ? 5 : 4);
   hipLaunchKernelGGL(wino_persist16_kernel, dim3(256), dim3(512), kWino16Lds, stream, pa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;

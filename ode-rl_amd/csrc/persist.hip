@@ -357,7 +357,9 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
       small16 = on16;
       for (int i = 0; i < rec_.count && small16; ++i) {
         const ConvArgs& a = rec_.items[i];
-        small16 = a.qin == 16 && a.qout == 16 && (a.combine == 0 || (a.combine == 1 && a.h_by_value && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order));
+        small16 = a.qin == 16 && a.qout == 16 &&
+                  (a.combine == 0 || a.combine == 2 || a.combine == 3 ||
+                   (a.combine == 1 && a.h_by_value && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order));
       }
     }
     if (table) {
