@@ -236,10 +236,15 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
   typedef StageProgram<METHOD> Prog;
   constexpr int S = Prog::S;
   constexpr int NK = Prog::n_prev[S - 1];   // stage derivatives that must be kept (rk4: 3, midpoint / euler: 0)
+  // TWO activation tiles (round 3): a layer reads one and writes its output into the other, so no wave has to wait for the slowest
+  // reader before it rewrites -- the in-place rewrite of the single-tile kernels needs a barrier of its own per layer and
+  // serialises the epilogue behind it.  Both fit next to the weight ring because a tile here has NO column borders: the dx = -1 /
+  // +1 taps are lane shifts of the centre fragment whose shifted-in lane is zero, columns 0 and 17 of the [18][18] tile were never
+  // read.  [18 rows][16 columns][64 ch + pad]: 41,472 B each.
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const act = smem;
-  char* const ring = smem + kFTile;
-  float* const bias_l = (float*)(smem + kFTile + kFStages * kFUnit);
+  char* const ring = smem + 2 * kTTile;
+  float* const bias_l = (float*)(smem + 2 * kTTile + kFStages * kFUnit);
+  int cur = 0;   // the tile the next layer reads (wave-uniform)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x;
@@ -257,33 +262,31 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
   issue(1 % UE, 1);
 
   for (int i = threadIdx.x; i < NL * 64; i += 512) bias_l[i] = ta.bias[i >> 6] ? ta.bias[i >> 6][i & 63] : 0.0f;
-  for (int i = threadIdx.x; i < 68 * 9; i += 512) {  // zero border of the tile
+  for (int i = threadIdx.x; i < 64 * 9; i += 512) {  // zero row borders (rows 0 and 17) of both tiles
     const int p = i / 9, c16 = i % 9;
-    int row, col;
-    if (p < 18) { row = 0; col = p; }
-    else if (p < 36) { row = 17; col = p - 18; }
-    else if (p < 52) { row = p - 36 + 1; col = 0; }
-    else { row = p - 52 + 1; col = 17; }
-    *(f32x4*)(act + (row * 18 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tile = p >> 5, row = (p & 16) ? 17 : 0, col = p & 15;
+    *(f32x4*)(smem + tile * kTTile + (row * 16 + col) * kFS + c16 * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
   const int i32 = lane & 31, kq = lane >> 5;
   const int px = i32 & 15, pyl = i32 >> 4;
   const int mb = wave & 1, row0 = (wave >> 1) * 4 + pyl;
   const int P0 = row0 * 16 + px, P1 = P0 + 32;
-  const char* const in = act + ((row0 + 1) * 18 + px + 1) * kFS + kq * 16;
+  const int in_off = ((row0 + 1) * 16 + px) * kFS + kq * 16;
 
   // solver state: y[nb][4g + j] = channel 32 mb + 8 g + 4 kq + j of pixel (nb ? P1 : P0) -- the accumulator layout
   f32x16 y[2], k[NK > 0 ? NK : 1][2];
   // channels of quad Q = 8 mb + 2 g + kq as bf16: into the activation tile and, if `dst` (wave-uniform: this sample's Q4h tensor),
   // into HBM -- one lane offset, the quads 4 KiB apart
   const unsigned q4h_off = (unsigned)(((mb * 8 + kq) * kPix + P0) * 8);
+  // written into the tile the CURRENT layer does not read (cur ^ 1); the caller flips `cur` once both pixel blocks are out
   auto emit = [&](const f32x16& v, int nb, char* dst) {
+    char* const wt = smem + (cur ^ 1) * kTTile;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int Q = mb * 8 + 2 * g + kq;
       const u32x2 pk = {pk_bf16(v[4 * g], v[4 * g + 1]), pk_bf16(v[4 * g + 2], v[4 * g + 3])};
-      *(u32x2*)(act + ((row0 + 2 * nb + 1) * 18 + px + 1) * kFS + Q * 8) = pk;
+      *(u32x2*)(wt + ((row0 + 2 * nb + 1) * 16 + px) * kFS + Q * 8) = pk;
       if (SAVE && dst) *(u32x2*)(dst + (q4h_off + (unsigned)(g * 2 * kPix * 8 + nb * 32 * 8))) = pk;
     }
   };
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
     }
     emit(y[nb], nb, save_x);
   }
+  cur ^= 1;
 
   long long u = 0;
   int frame_pending = 0;   // the previous stage stored a result frame: 32 more stores younger than the first two units' DMAs (wave-uniform)
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
     for (int s = 0; s < S; ++s) {
       const size_t ev = (size_t)n * S + s;
       for (int e = 0; e < NL; ++e) {
+        const char* const in = smem + cur * kTTile + in_off;
 #pragma unroll
         for (int r = 0; r < 3; ++r, ++u) {
           // unit u landed?  Younger than its DMAs: the next unit's three DMAs and -- for the first two units of a layer -- what was
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) xc[nb][cb] = *(const u32x4*)(in + ((r - 1) * 18 + nb * 36) * kFS + cb * 32);
+            for (int cb = 0; cb < 4; ++cb) xc[nb][cb] = *(const u32x4*)(in + ((r - 1) * 16 + nb * 32) * kFS + cb * 32);
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const char* wb = ring + r * kFUnit + c * 8192 + mb * 1024 + vw;
@@ -361,9 +366,8 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
           }
         }
         if (e == 0) frame_pending = 0;
-        // every wave has read the tile: rewrite it in place (hidden layer: ReLU; last layer: the next stage input / new state)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // the output goes to the OTHER tile: no wave has to be waited for (hidden layer: ReLU; last layer: the next stage input /
+        // new state, below); the first barrier of the next layer makes it visible
         if (e < NL - 1) {
           char* const dst = SAVE ? wave_uniform(save_h + ev * ta.stride_h_eval + (size_t)e * ta.stride_h_layer) : nullptr;
 #pragma unroll
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
             for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
             emit(v, nb, dst);
           }
+          cur ^= 1;
         }
       }
       // ---- stage combine (conv_common.h::epilogue, combine == 1): kc = k_scale * f(x_s);  out = y + h * (c[n_prev] kc + sum_j c[j] k_j)
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
         }
         emit(o, nb, last_eval ? nullptr : dst);
       }
+      cur ^= 1;
       if (final_stage) frame_pending = 1;
     }
   }
@@ -435,7 +441,7 @@ static int launch_ftraj(const TrajArgs& ta, int batch, hipStream_t stream) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)ftraj_bf16_kernel<METHOD, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((ftraj_bf16_kernel<METHOD, SAVE>), dim3(batch), dim3(512), kFusedLds, stream, ta);
+  hipLaunchKernelGGL((ftraj_bf16_kernel<METHOD, SAVE>), dim3(batch), dim3(512), kTrajLds, stream, ta);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

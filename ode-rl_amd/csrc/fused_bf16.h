@@ -22,6 +22,10 @@ constexpr int kFUnit = 3 * 8192;           // one kernel row (3 taps) of one lay
 constexpr int kFStages = 3;
 constexpr int kFBias = ODEHIP_MAX_LAYERS * 64 * 4;  // every layer's bias, staged once (a global load per layer would sit in front of the ring's vmcnt waits)
 constexpr int kFusedLds = kFTile + kFStages * kFUnit + kFBias;
+// the whole-trajectory forward kernels: two tiles without column borders (fstack_bf16.hip, ftraj_bf16_kernel)
+constexpr int kTTile = 18 * 16 * kFS;      // 41,472 B
+constexpr int kTrajLds = 2 * kTTile + kFStages * kFUnit + kFBias;
+static_assert(kTrajLds <= 160 * 1024, "two activation tiles, the weight ring and the biases must fit the CU's LDS");
 
 // issued without the compiler's own s_waitcnt bookkeeping: the ring's counted waits cover it (see wait_younger)
 __device__ __forceinline__ f32x4 gload_untracked(const float* p) {
