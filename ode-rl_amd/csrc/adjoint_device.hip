@@ -607,6 +607,7 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
   }
   if (g_adj_mailbox->status != 0) {
     const int s = g_adj_mailbox->status;
+    ODEHIP_CHECK_HIP(hipStreamSynchronize(stream));   // (error path: nothing of this call may still write the mailbox afterwards)
     if (s == ODEHIP_ENAN) set_error("odeint_adjoint_dopri5_backward: non-finite error ratio");
     else if (s == ODEHIP_ENOTCONV) set_error("odeint_adjoint_dopri5_backward: underflow in dt");
     else set_error("odeint_adjoint_dopri5_backward: more than max_accept = %d accepted steps", max_accept);
@@ -621,7 +622,7 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
   float* slabs = L.p(ws, L.off_slab);
   const WgradPair* wt = (const WgradPair*)L.p(ws, L.off_wtab);
   for (int l = 0; l < NL; ++l) {
-    rc = launch_wgrad(wt + (size_t)l * init.wtab_cap, n_eval, batch, 4, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream,
+    rc = launch_wgrad(wt + (size_t)l * init.wtab_cap, n_eval, batch, wgrad_esplit(batch, n_eval), slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream,
                       f->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
@@ -639,6 +640,16 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
     regions[nr] = grad_b[l]; floats[nr++] = (size_t)f->channels[l + 1];
   }
   if ((rc = persist.guard(regions, floats, nr, stream)) != ODEHIP_OK) return rc;
+  // A tick may still be queued behind `done` (the host runs one ahead): its controller writes the mailbox once more.  Wait for it
+  // (the work enqueued above keeps the device busy meanwhile) so that the next call's freshly cleared mailbox cannot be overwritten
+  // by this call's last controller.
+  t_progress = adj_now_s();
+  while (g_adj_mailbox->ticks < enq) {
+    if (adj_now_s() - t_progress > 120.0) {
+      set_error("odeint_adjoint_dopri5_backward: the device did not drain (%d of %d ticks)", g_adj_mailbox->ticks, enq);
+      return ODEHIP_EHIP;
+    }
+  }
   *ran = 1;
   return ODEHIP_OK;
 }

@@ -32,7 +32,7 @@ struct AdjLayout {
     off_ka = take(7 * st);
     off_slots = take((size_t)max_slots * slot_bytes);
     off_tab = take((size_t)max_slots * 7 * sizeof(WgradPair));
-    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
+    off_slab = take(((size_t)B * wgrad_esplit_max(B) + 1) * kWgradSlabFloats * 4);
     P = 0;
     for (int l = 0; l < f->n_convs; ++l) P += f->channels[l + 1] * f->channels[l] * 9 + f->channels[l + 1];
     off_theta = take((size_t)5 * P * 4);  // mixed norm: running a_theta, error estimate, increment, K^theta at the two initial-step points

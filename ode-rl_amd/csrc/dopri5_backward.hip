@@ -339,7 +339,7 @@ static int dopri5_backward(const odehip_convstack* f, const odehip_convstack* f_
   }
   if ((rc = staged_upload(table, host.data(), host.size() * sizeof(WgradPair), stream)) != ODEHIP_OK) return rc;
   for (int l = 0; l < NL; ++l) {
-    rc = launch_wgrad(table + (size_t)l * n_eval, n_eval, batch, 4, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream,
+    rc = launch_wgrad(table + (size_t)l * n_eval, n_eval, batch, f->w_bf16[l] ? 4 : wgrad_esplit(batch, n_eval), slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream,
                       f->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }

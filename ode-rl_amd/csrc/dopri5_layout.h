@@ -31,7 +31,7 @@ struct BwdLayout {
     off_slots = take((size_t)(N > 0 ? N : 1) * slot_bytes);
     off_tab = take(((size_t)N * 6 + 1) * sizeof(WgradPair) * ODEHIP_MAX_LAYERS);
     off_psync = take(persist_sync_bytes(B));
-    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
+    off_slab = take(((size_t)B * wgrad_esplit_max(B) + 1) * kWgradSlabFloats * 4);
     total = o;
   }
   float* p(const void* ws, size_t off) const { return (float*)((char*)const_cast<void*>(ws) + off); }

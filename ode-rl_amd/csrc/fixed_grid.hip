@@ -58,8 +58,8 @@ struct FixedLayout {
       off_go = take((size_t)T * st);       // grad_out in Q4
       off_gy = take(st);
       off_g2 = take(2 * st);
-      off_tab = take(ne * sizeof(WgradPair));
-      off_slab = take(((size_t)B * kEsplit + 1) * kWgradSlabFloats * 4);
+      off_tab = take(ne * sizeof(WgradPair) * ODEHIP_MAX_LAYERS);   // one table per layer, uploaded together
+      off_slab = take(((size_t)B * wgrad_esplit_max(B) + 1) * kWgradSlabFloats * 4);
     }
     total = o;
   }
@@ -125,30 +125,23 @@ static int wgrad_all_layers(const odehip_convstack* f, const FixedLayout& L, voi
   ODEHIP_REQUIRE(n_eval <= 32 * 64, "odeint backward: too many evaluations (%d)", n_eval);
   WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
   float* slabs = L.p(ws, L.off_slab);
-  for (int l = 0; l < NL && !(g_debug_flags & 32); ++l) {
-    // 4 u64 per table entry (g, a, scale bits, 0), uploaded through kernel arguments
-    for (int o = 0; o < 4 * n_eval; o += 32) {
-      PtrPack pk;
-      const int m = 4 * n_eval - o < 32 ? 4 * n_eval - o : 32;
-      for (int i = 0; i < m; ++i) {
-        const int e = (o + i) / 4, n = e / S, s = e % S, field = (o + i) & 3;
-        unsigned long long v = 0;
-        if (field == 0) {
-          v = (unsigned long long)(uintptr_t)L.gp(ws, n, s, l);
-        } else if (field == 1) {
-          const float* a = l > 0 ? L.hidden(ws, n, s, l - 1) : (s > 0 ? L.xin(ws, n, s) : L.y(ws, adjoint ? n + 1 : n));
-          v = (unsigned long long)(uintptr_t)a;
-        } else if (field == 2) {
-          const float sc = eval_scale ? eval_scale[e] : 1.0f;
-          unsigned u;
-          memcpy(&u, &sc, 4);
-          v = u;
-        }
-        pk.v[i] = v;
-      }
-      hipLaunchKernelGGL(fill_u64_kernel, dim3(1), dim3(32), 0, stream, (unsigned long long*)table + o, pk, m);
+  // the NL tables (g, a, scale per evaluation) travel in ONE asynchronous staged upload (25 kernel-argument uploads per training step before)
+  std::vector<WgradPair> host((size_t)NL * n_eval);
+  for (int l = 0; l < NL; ++l)
+    for (int e = 0; e < n_eval; ++e) {
+      const int n = e / S, s = e % S;
+      WgradPair& p = host[(size_t)l * n_eval + e];
+      p.g = L.gp(ws, n, s, l);
+      p.a = l > 0 ? L.hidden(ws, n, s, l - 1) : (s > 0 ? L.xin(ws, n, s) : L.y(ws, adjoint ? n + 1 : n));
+      p.scale = eval_scale ? eval_scale[e] : 1.0f;
+      p.pad_[0] = p.pad_[1] = p.pad_[2] = 0.0f;
     }
-    int rc = launch_wgrad(table, n_eval, batch, kEsplit, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream, f->w_bf16[l] != nullptr);
+  int rc = staged_upload(table, host.data(), host.size() * sizeof(WgradPair), stream);
+  if (rc != ODEHIP_OK) return rc;
+  const int esplit = f->w_bf16[0] ? kEsplit : wgrad_esplit(batch, n_eval);
+  for (int l = 0; l < NL && !(g_debug_flags & 32); ++l) {
+    rc = launch_wgrad(table + (size_t)l * n_eval, n_eval, batch, esplit, slabs, grad_w[l], grad_b[l], f->channels[l + 1], f->channels[l], stream,
+                      f->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
   return ODEHIP_OK;

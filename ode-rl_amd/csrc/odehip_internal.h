@@ -197,6 +197,15 @@ struct WgradPair {
 // floats per workgroup slab of the weight-gradient kernels: the Winograd-domain tile [16 positions][64][64] + 64 bias sums is the
 // largest; every slab region holds batch * esplit of them PLUS ONE (the fixed-order sum before the final G^T . G)
 constexpr int kWgradSlabFloats = 16 * 64 * 64 + 64;
+// Workgroups per sample of a batched weight-gradient launch (each walks every esplit-th evaluation): 4 at the batches the chip is
+// full anyway; small batches split the evaluations further so that the launch still covers the CUs (B = 4: 16 workgroups walked
+// nine evaluations each -- 215 us per layer, the time of a B = 64 launch).  At most 256 slabs, as at B = 64.
+inline int wgrad_esplit(int batch, int n_eval) {
+  int e = batch > 0 ? 256 / batch : 4;
+  if (e > n_eval) e = n_eval;
+  return e < 4 ? 4 : e;
+}
+inline int wgrad_esplit_max(int batch) { return batch >= 64 ? 4 : (256 / batch < 4 ? 4 : 256 / batch); }
 int launch_wgrad_wino(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
                       int cin, hipStream_t stream);  // wgrad_wino.hip; 1 = switched off
 int launch_wgrad(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cout,
