@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256) void init2_kernel(DopriState* st, const float*
 
 // _adaptive_step's scalar part: error ratio, accept, output range, next dt (torchdiffeq _optimal_step_size)
 __global__ __launch_bounds__(256) void controller_kernel(DopriState* st, const float* partials, const double* t_out,
-                                                          Mailbox* mb) {
+                                                          Mailbox* mb, unsigned* psync, int psync_words) {
   __shared__ float sh[256];
+  // the flag area of the NEXT attempt's persistent walk (this attempt's walk has finished: stream order) -- saves a memset launch
+  for (int i = threadIdx.x; i < psync_words; i += 256) psync[i] = 0u;
   if (st->done) {  // an attempt the host enqueued after the solve finished: only acknowledge it
     if (threadIdx.x == 0) {
       st->accept = 0;
@@ -600,6 +602,7 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   fa.off_y1 = (long long)(6 * BL.st);
   fa.off_x2 = (long long)(1 * BL.st);
 
+  ODEHIP_CHECK_HIP(hipMemsetAsync(psync, 0, persist_sync_bytes(batch), stream));   // first attempt's flag area; the controller zeroes it for the next
   // ---- attempted steps; the host runs at most RUN_AHEAD attempts ahead of the device
   // one attempt queued behind the running one keeps the GPU busy (enqueue ~0.1 ms < attempt ~0.4 ms).  Exact-global mode
   // enqueues a collective per attempt, so every rank must enqueue the same number of attempts: no run-ahead there.
@@ -641,13 +644,14 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
       if (rc != ODEHIP_OK) return rc;
     }
     if (saving) persist.set_device_steering(nullptr, reloc);
-    if ((rc = persist.finish(nullptr, nullptr, nullptr, batch, psync, f->ks, stream)) != ODEHIP_OK) return rc;
+    if ((rc = persist.finish(nullptr, nullptr, nullptr, batch, psync, f->ks, stream, /*sync_is_zero=*/true)) != ODEHIP_OK) return rc;
     if (global_norm) {
       const float* arr[1] = {part0};
       const int lens[1] = {n_conv_partials};
       if ((rc = reduce_sums(1, arr, lens, nullptr)) != ODEHIP_OK) return rc;
     }
-    hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, global_norm ? g_reduce_buf : part0, t_dev, g_mailbox);
+    hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, global_norm ? g_reduce_buf : part0, t_dev, g_mailbox, psync,
+                       (int)(persist_sync_bytes(batch) / 4));
     hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, stream, fa, n4, (float)dp5::kCMid[0], (float)dp5::kCMid[2],
                        (float)dp5::kCMid[3], (float)dp5::kCMid[4], (float)dp5::kCMid[5], (float)dp5::kCMid[6]);
     ODEHIP_CHECK_HIP(hipGetLastError());
