@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 7 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 8 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -356,6 +356,19 @@ int odehip_odeint_dopri5_backward_saved(const odehip_convstack* f, const odehip_
                                         int batch, const double* accepted_host, int n_steps, const float* grad_out_nchw,
                                         float* grad_z0_nchw, float* const* grad_w, float* const* grad_b, int max_accept,
                                         void* saved_workspace, size_t saved_workspace_bytes, void* stream);
+
+/* The ASYNCHRONOUS pair (ABI 8).  odehip_odeint_dopri5 / _saving return only when the device-side controller has reported
+ * completion -- the host cannot enqueue the work BEHIND the solver (decoder, loss, the backward pass) meanwhile, and in a whole
+ * training step the device then idles while ~600 launches are enqueued.  odehip_odeint_dopri5_start takes _saving's arguments
+ * (max_accept = 0: nothing is kept for a backward pass), enqueues `attempts` attempted steps (those queued behind completion
+ * return at once) and comes back WITHOUT waiting: no stats, no status.  odehip_odeint_dopri5_collect(token) waits for the device
+ * (normally long done), enqueues further attempts should the solve need them, and reports what the synchronous call reports --
+ * including ODEHIP_ENOTCONV / ODEHIP_ENAN, i.e. an error surfaces at collect time.  Everything start was given (workspace, out,
+ * z0) must stay untouched until collect; at most 4 solves may be pending; not available under exact-global step control. */
+int odehip_odeint_dopri5_start(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
+                               float rtol, float atol, double first_step, int max_steps, float* out_nchw, int max_accept,
+                               int attempts, int* token_out, void* workspace, size_t workspace_bytes, void* stream);
+int odehip_odeint_dopri5_collect(int token, int* stats_host, double* accepted_host, int accepted_cap, int* saved_out);
 
 /* ---- optimizer step of the training loop (train_test.py:24,205: optim.Adam(model.parameters(), lr)) ------------------------ */
 

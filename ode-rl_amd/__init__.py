@@ -5,7 +5,7 @@ Public surface = the reference's: `odeint`, `DiffEqSolver`, `ODEFunc`, `create_c
 from . import _lib  # noqa: F401
 from .odeint import odeint, last_stats  # noqa: F401
 from .autograd import odeint_adjoint, last_adjoint_stats  # noqa: F401
-from .hip_ops import set_compute_dtype, current_compute_dtype  # noqa: F401
+from .hip_ops import set_compute_dtype, current_compute_dtype, set_async_dopri5, collect_pending_solves  # noqa: F401
 from .helpers.utils import create_convnet  # noqa: F401
 from .modules.DiffEqSolver import DiffEqSolver, ODEFunc  # noqa: F401
 from .modules.ConvGRUCell import ConvGRUCell  # noqa: F401

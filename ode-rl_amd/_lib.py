@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
-ABI_VERSION = 7   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
+ABI_VERSION = 8   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
 MAX_LAYERS = 8
 MAX_STAGES = 7
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
@@ -206,6 +206,12 @@ SIGNATURES = {
                                                    ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double),
                                                    ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
                                                    ctypes.c_size_t, ctypes.c_void_p]),
+    "odehip_odeint_dopri5_start": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_double, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                                                  ctypes.c_size_t, ctypes.c_void_p]),
+    "odehip_odeint_dopri5_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), ctypes.c_int,
+                                                    ctypes.POINTER(ctypes.c_int)]),
     "odehip_odeint_dopri5_backward_saved": (ctypes.c_int, [ctypes.POINTER(ConvStack), ctypes.POINTER(ConvStack),
                                                            ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_int,
                                                            ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

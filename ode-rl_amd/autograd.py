@@ -50,14 +50,20 @@ class _Dopri5Odeint(torch.autograd.Function):
         out, stats, ctx.saved = hip_ops.odeint_dopri5_saving(stack, y0d, t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
                                                              max_steps=cfg["max_num_steps"])
         from .odeint import last_stats
-        last_stats.clear()
-        last_stats.update(stats)
-        if stats["n_accept"] > len(stats["accepted"]):
-            raise RuntimeError(f"odeint(HIP, dopri5): {stats['n_accept']} accepted steps exceed the {hip_ops.LOG_CAP} "
-                               "the backward pass can re-integrate")
-        ctx.stack, ctx.t_host, ctx.accepted = stack, t_host, stats["accepted"]
+        ctx.stack, ctx.t_host = stack, t_host
         ctx.versions = tuple(p._version for p in params)
         ctx.params = params
+        if isinstance(stats, hip_ops.PendingDopri5):   # asynchronous solve: nothing is known yet -- the backward pass collects it
+            last_stats._bind(stats)
+            ctx.pending, ctx.accepted = stats, None
+        else:
+            ctx.pending = None
+            last_stats.clear()
+            last_stats.update(stats)
+            if stats["n_accept"] > len(stats["accepted"]):
+                raise RuntimeError(f"odeint(HIP, dopri5): {stats['n_accept']} accepted steps exceed the {hip_ops.LOG_CAP} "
+                                   "the backward pass can re-integrate")
+            ctx.accepted = stats["accepted"]
         ctx.save_for_backward(y0d)
         return out
 
@@ -67,6 +73,13 @@ class _Dopri5Odeint(torch.autograd.Function):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
         (y0,) = ctx.saved_tensors
+        if ctx.pending is not None:
+            stats, ctx.saved = ctx.pending.collect()
+            ctx.pending = None
+            if stats["n_accept"] > len(stats["accepted"]):
+                raise RuntimeError(f"odeint(HIP, dopri5): {stats['n_accept']} accepted steps exceed the {hip_ops.LOG_CAP} "
+                                   "the backward pass can re-integrate")
+            ctx.accepted = stats["accepted"]
         if ctx.saved is not None and len(ctx.accepted) >= 1:
             gz0, gws, gbs = hip_ops.odeint_dopri5_backward_saved(ctx.stack, ctx.t_host, ctx.accepted, grad_out, ctx.saved)
             ctx.saved = None
@@ -192,11 +205,16 @@ class _AdjointDopri5(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y0, t_host, cfg, stack, *params):
         ctx.mode = hip_ops.current_compute_dtype()
-        out, stats = hip_ops.odeint_dopri5(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"],
-                                           first_step=cfg["first_step"], max_steps=cfg["max_num_steps"])
         from .odeint import last_stats
-        last_stats.clear()
-        last_stats.update(stats)
+        if hip_ops._async_dopri5:
+            out, pending = hip_ops.odeint_dopri5_start(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
+                                                       max_steps=cfg["max_num_steps"])
+            last_stats._bind(pending)
+        else:
+            out, stats = hip_ops.odeint_dopri5(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"],
+                                               first_step=cfg["first_step"], max_steps=cfg["max_num_steps"])
+            last_stats.clear()
+            last_stats.update(stats)
         ctx.stack, ctx.t_host, ctx.cfg = stack, t_host, cfg
         ctx.versions = tuple(p._version for p in params)
         ctx.params = params

@@ -341,13 +341,6 @@ __global__ void init_state_kernel(DopriState* st, float rtol, float atol, int n_
   *st = z;
 }
 
-static Mailbox* g_mailbox = nullptr;
-
-// exact-global step control under batch sharding: every sum of squares is summed over the ranks before it is used
-static odehip_allreduce_fn g_reduce_cb = nullptr;
-static void* g_reduce_user = nullptr;
-static int g_reduce_world = 1;
-static float* g_reduce_buf = nullptr;
 
 // out[j] = fixed-order sum of partial array j (one workgroup)
 struct SumSet {
@@ -369,6 +362,184 @@ static double now_s() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+// ---- one dopri5 solve in flight.  The synchronous entry points build it on their stack and run it to completion; the asynchronous
+// pair (odehip_odeint_dopri5_start / _collect) parks it in a slot between the two calls, so that the host can go on enqueueing the
+// work behind the solver (decoder, loss, the whole backward pass) while the device is still integrating.
+struct D5Ctx {
+  bool in_use = false;
+  odehip_convstack f;          // by value: the caller's descriptor need not outlive the start call
+  int n_times = 0, batch = 0, n_conv_partials = 0;
+  float rtol = 0, atol = 0, ksc = 1;
+  hipStream_t stream = nullptr;
+  DopriState* state = nullptr;
+  double* t_dev = nullptr;
+  float *part0 = nullptr, *ping = nullptr, *pong = nullptr, *xs = nullptr, *y = nullptr, *y1 = nullptr, *k[7] = {};
+  unsigned* psync = nullptr;
+  unsigned long long* reloc = nullptr;
+  bool saving = false, global_norm = false;
+  size_t bl_st = 0, bl_hid = 0;   // BwdLayout::st / hid / NH of the saving slots
+  int bl_nh = 0;
+  FinishArgs fa;
+  long long n4 = 0;
+  Mailbox* mb = nullptr;
+  int enq = 0, seen = 0;
+  double t_progress = 0;
+};
+constexpr int kD5Slots = 4;
+static D5Ctx g_d5[kD5Slots];
+static Mailbox* g_d5_mailbox[kD5Slots + 1] = {};   // [kD5Slots]: the synchronous calls'
+
+static int d5_mailbox(int slot, Mailbox** out) {
+  if (!g_d5_mailbox[slot]) {
+    // 64 KiB of pinned, coherent host memory for the controller's progress word and its log of accepted steps
+    ODEHIP_CHECK_HIP(hipHostMalloc((void**)&g_d5_mailbox[slot], kMailboxBytes, hipHostMallocCoherent));
+  }
+  memset((void*)g_d5_mailbox[slot], 0, sizeof(Mailbox));
+  *out = g_d5_mailbox[slot];
+  return ODEHIP_OK;
+}
+
+// exact-global step control under batch sharding: every sum of squares is summed over the ranks before it is used
+static odehip_allreduce_fn g_reduce_cb = nullptr;
+static void* g_reduce_user = nullptr;
+static int g_reduce_world = 1;
+static float* g_reduce_buf = nullptr;
+static int d5_reduce_sums(hipStream_t stream, int count, const float* const* arrays, const int* lens, const int* skip_flag) {
+  SumSet ss;
+  memset(&ss, 0, sizeof(ss));
+  ss.count = count;
+  for (int j = 0; j < count; ++j) {
+    ss.p[j] = arrays[j];
+    ss.n[j] = lens[j];
+  }
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, ss, g_reduce_buf, skip_flag);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  const int rcb = g_reduce_cb(g_reduce_buf, count, (void*)stream, g_reduce_user);
+  ODEHIP_REQUIRE(rcb == 0, "odeint_dopri5: the all-reduce callback failed (%d)", rcb);
+  return ODEHIP_OK;
+}
+
+// enqueue ONE attempted step: the six evaluations (one persistent launch: the same table for every attempt -- the step size is read
+// through h_ptr, the queued-behind-`done` case through the skip word), the controller, the elementwise tail
+static int d5_attempt(D5Ctx& x) {
+  const odehip_convstack* f = &x.f;
+  int rc;
+  constexpr unsigned long long kTag1 = 1ull << 56;
+  auto s_xin = [&](int e) { return (float*)(kTag1 | (unsigned long long)((size_t)e * x.bl_st)); };
+  auto s_hid = [&](int e, int l) { return (float*)(kTag1 | (unsigned long long)(7 * x.bl_st + ((size_t)e * x.bl_nh + l) * x.bl_hid)); };
+  const int* skip = &x.state->done;
+  PersistScope persist;
+  if ((rc = persist.begin(f, nullptr, 6 * f->n_convs)) != ODEHIP_OK) return rc;
+  CombineArgs c;
+  for (int s = 2; s <= 7; ++s) {  // k_s = f(x_s); fused: x_{s+1} = y + h*sum beta_{s+1,j} k_j   (s = 7: error norm)
+    memset(&c, 0, sizeof(c));
+    c.k_scale = x.ksc;
+    c.order = all_64(f);   // 64-channel stacks: the adaptive walk (stage sums formed ahead of the matrix work), same bits per layer
+    c.y = x.y;
+    c.h_ptr = &x.state->h;
+    c.n_prev = s - 1;
+    for (int j = 0; j < s - 1; ++j) c.k_prev[j] = x.k[j];
+    c.k_out = x.k[s - 1];
+    if (s <= 6) {
+      for (int j = 0; j < s; ++j) c.c1[j] = (float)dp5::kBeta[s - 1][j];
+      c.out1 = x.saving ? s_xin(s) : (s < 6 ? x.xs : x.y1);  // x7 = y1 (c_sol equals the last beta row)
+    } else {
+      for (int j = 0; j < 7; ++j) c.ce[j] = (float)dp5::kCErr[j];
+      c.err_y1 = x.saving ? s_xin(6) : x.y1;
+      c.err_partials = x.part0;
+      c.rtol = x.rtol;
+      c.atol = x.atol;
+    }
+    if (x.saving) {   // evaluation (slot, s - 1): input and hidden activations live in the slot the device picks
+      ODEHIP_REQUIRE(persist.recording(), "odeint_dopri5: the persistent walk became unavailable during a saving forward");
+      float* hid_s[ODEHIP_MAX_LAYERS];
+      for (int l = 0; l < x.bl_nh; ++l) hid_s[l] = s_hid(s - 1, l);
+      rc = enqueue_f_saving(f, s_xin(s - 1), x.batch, hid_s, x.ping, x.pong, &c, nullptr, skip, x.stream);
+    } else {
+      rc = enqueue_f(f, s < 7 ? x.xs : x.y1, x.batch, x.ping, x.pong, &c, nullptr, skip, x.stream);
+    }
+    if (rc != ODEHIP_OK) return rc;
+  }
+  if (x.saving) persist.set_device_steering(nullptr, x.reloc);
+  if ((rc = persist.finish(nullptr, nullptr, nullptr, x.batch, x.psync, f->ks, x.stream, /*sync_is_zero=*/true)) != ODEHIP_OK) return rc;
+  if (x.global_norm) {
+    const float* arr[1] = {x.part0};
+    const int lens[1] = {x.n_conv_partials};
+    if ((rc = d5_reduce_sums(x.stream, 1, arr, lens, nullptr)) != ODEHIP_OK) return rc;
+  }
+  hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, x.stream, x.state, x.global_norm ? g_reduce_buf : x.part0, x.t_dev, x.mb, x.psync,
+                     (int)(persist_sync_bytes(x.batch) / 4));
+  hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, x.stream, x.fa, x.n4, (float)dp5::kCMid[0], (float)dp5::kCMid[2],
+                     (float)dp5::kCMid[3], (float)dp5::kCMid[4], (float)dp5::kCMid[5], (float)dp5::kCMid[6]);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  ++x.enq;
+  return ODEHIP_OK;
+}
+
+// attempts until the controller reports done (the host at most RUN_AHEAD attempts ahead of the device: one attempt queued behind the
+// running one keeps the GPU busy; exact-global mode enqueues a collective per attempt, so every rank must enqueue the same number:
+// no run-ahead there), then wait for the last enqueued controller so that the mailbox is final
+static int d5_run_to_done(D5Ctx& x) {
+  const int RUN_AHEAD = x.global_norm ? 0 : 1;
+  int rc;
+  x.t_progress = now_s();
+  auto stalled = [&](const char* what) {
+    if (x.mb->steps_done != x.seen) {   // the limit is on time WITHOUT progress, not on the whole integration
+      x.seen = x.mb->steps_done;
+      x.t_progress = now_s();
+    }
+    if (now_s() - x.t_progress > 120.0) {
+      set_error("odeint_dopri5: %s (steps done %d of %d enqueued)", what, x.mb->steps_done, x.enq);
+      return true;
+    }
+    return false;
+  };
+  for (;;) {
+    while (!x.mb->done && x.mb->steps_done + RUN_AHEAD < x.enq)
+      if (stalled("no progress from the device for 120 s")) return ODEHIP_EHIP;
+    if (x.mb->done) break;
+    if ((rc = d5_attempt(x)) != ODEHIP_OK) return rc;
+  }
+  // attempts enqueued after `done` do nothing (skip flag)
+  while (x.mb->steps_done < x.enq)
+    if (stalled("device did not drain")) return ODEHIP_EHIP;
+  return ODEHIP_OK;
+}
+
+static int d5_collect(D5Ctx& x, int* stats_host, double* accepted_host, int accepted_cap, int* saved_out) {
+  // the device has finished every attempt of this call: a persistent launch that gave up a wait is known NOW
+  if (const unsigned code = persist_error(true)) {
+    set_error("odeint_dopri5: a persistent launch gave up waiting for a partner workgroup (code %u); the trajectory is invalid.  "
+              "Persistent launches are now disabled for this process", code);
+    return ODEHIP_EHIP;
+  }
+  Mailbox* mb = x.mb;
+  if (saved_out) *saved_out = x.saving && mb->save_ok && mb->status == 0;
+  if (stats_host) {
+    stats_host[0] = mb->nfe;
+    stats_host[1] = mb->n_accept;
+    stats_host[2] = mb->n_reject;
+    stats_host[3] = x.enq;
+  }
+  if (accepted_host) {  // (t0, dt) pairs; the caller sees from stats_host[1] > accepted_cap that the log is incomplete
+    int n = mb->n_accept < kLogCap ? mb->n_accept : kLogCap;
+    if (n > accepted_cap) n = accepted_cap;
+    for (int i = 0; i < n; ++i) {
+      accepted_host[2 * i] = mb->log[i][0];
+      accepted_host[2 * i + 1] = mb->log[i][1];
+    }
+  }
+  if (mb->status == ODEHIP_ENAN) {
+    set_error("odeint_dopri5: non-finite error ratio (non-finite values in state `y`)");
+    return ODEHIP_ENAN;
+  }
+  if (mb->status == ODEHIP_ENOTCONV) {
+    set_error("odeint_dopri5: underflow in dt or max_num_steps exceeded");
+    return ODEHIP_ENOTCONV;
+  }
+  return ODEHIP_OK;
 }
 
 
@@ -412,7 +583,7 @@ extern "C" size_t odehip_dopri5_saving_workspace_bytes(const odehip_convstack* f
 static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch, float rtol,
                           float atol, double first_step, int max_steps, int negate, float* out_nchw, int* stats_host,
                           double* accepted_host, int accepted_cap, void* workspace, size_t workspace_bytes, void* stream_,
-                          int save_max_accept, int* saved_out);
+                          int save_max_accept, int* saved_out, int async_attempts = 0, int* token_out = nullptr);
 
 extern "C" int odehip_odeint_dopri5(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times,
                                     int batch, float rtol, float atol, double first_step, int max_steps, int negate,
@@ -437,7 +608,7 @@ extern "C" int odehip_odeint_dopri5_saving(const odehip_convstack* f, const floa
 static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch, float rtol,
                           float atol, double first_step, int max_steps, int negate, float* out_nchw, int* stats_host,
                           double* accepted_host, int accepted_cap, void* workspace, size_t workspace_bytes, void* stream_,
-                          int save_max_accept, int* saved_out) {
+                          int save_max_accept, int* saved_out, int async_attempts, int* token_out) {
   int rc = check_stack(f);
   if (rc != ODEHIP_OK) return rc;
   ODEHIP_REQUIRE(z0_nchw && t_host && out_nchw && workspace, "odeint_dopri5: null pointer");
@@ -456,11 +627,19 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   const int n_conv_partials = batch * (C / 32) * 2 * 4;
   const int red_grid = 256;
 
-  if (!g_mailbox) {
-    // 64 KiB of pinned, coherent host memory for the controller's progress word and its log of accepted steps
-    ODEHIP_CHECK_HIP(hipHostMalloc((void**)&g_mailbox, kMailboxBytes, hipHostMallocCoherent));
+  // the context of this solve: on the stack for a synchronous call, in a free slot for an asynchronous one
+  D5Ctx stack_ctx;
+  int slot = kD5Slots;
+  if (async_attempts > 0) {
+    ODEHIP_REQUIRE(token_out && !g_reduce_cb, "odeint_dopri5_start: needs token_out; not available under exact-global step control");
+    slot = -1;
+    for (int i = 0; i < kD5Slots; ++i)
+      if (!g_d5[i].in_use) { slot = i; break; }
+    ODEHIP_REQUIRE(slot >= 0, "odeint_dopri5_start: %d solves are already pending (collect one first)", kD5Slots);
   }
-  memset((void*)g_mailbox, 0, sizeof(Mailbox));
+  D5Ctx& cx = slot < kD5Slots ? g_d5[slot] : stack_ctx;
+  cx = D5Ctx();
+  if ((rc = d5_mailbox(slot, &cx.mb)) != ODEHIP_OK) return rc;
 
   char* base = (char*)workspace;
   size_t off = 0;
@@ -480,7 +659,6 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   for (int i = 0; i < 7; ++i) k[i] = (float*)take(st_b);
   unsigned* psync = (unsigned*)take(persist_sync_bytes(batch));
   unsigned long long* reloc = (unsigned long long*)take(16 * 8);
-  const int* skip = &state->done;
 
   // ---- SAVING mode: every attempt writes its stage inputs and hidden activations into a slot of the backward workspace that
   // follows this one; the slot is chosen on the device (class-1 relocatable pointers), so the attempt's table is still the same
@@ -493,25 +671,11 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
     if ((rc = probe.begin(f, nullptr, 1)) != ODEHIP_OK) return rc;
     saving = probe.recording();
   }
-  constexpr unsigned long long kTag1 = 1ull << 56;
-  auto s_xin = [&](int e) { return (float*)(kTag1 | (unsigned long long)((size_t)e * BL.st)); };
-  auto s_hid = [&](int e, int l) { return (float*)(kTag1 | (unsigned long long)(7 * BL.st + ((size_t)e * BL.NH + l) * BL.hid)); };
 
   // exact-global mode: the kernels below read ONE already all-reduced scalar instead of the local partial arrays
   const bool global_norm = g_reduce_cb != nullptr;
   auto reduce_sums = [&](int count, const float* const* arrays, const int* lens, const int* skip_flag) -> int {
-    SumSet ss;
-    memset(&ss, 0, sizeof(ss));
-    ss.count = count;
-    for (int j = 0; j < count; ++j) {
-      ss.p[j] = arrays[j];
-      ss.n[j] = lens[j];
-    }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, ss, g_reduce_buf, skip_flag);
-    ODEHIP_CHECK_HIP(hipGetLastError());
-    const int rcb = g_reduce_cb(g_reduce_buf, count, stream_, g_reduce_user);
-    ODEHIP_REQUIRE(rcb == 0, "odeint_dopri5: the all-reduce callback failed (%d)", rcb);
-    return ODEHIP_OK;
+    return d5_reduce_sums(stream, count, arrays, lens, skip_flag);
   };
   hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, stream, state, rtol, atol, n_times,
                      global_norm ? 1 : n_conv_partials, (long long)st_f * (global_norm ? g_reduce_world : 1), max_steps,
@@ -529,6 +693,12 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   if (rc != ODEHIP_OK) return rc;
   if (saving) ODEHIP_CHECK_HIP(hipMemcpyAsync(BL.xin(bws, 0, 0), y, st_b, hipMemcpyDeviceToDevice, stream));   // stage input (0, 0) = z0
   if (n_times == 1) {
+    if (async_attempts > 0) {   // nothing to integrate: collect() only has to hand back empty stats
+      cx.n_times = 1;
+      cx.in_use = true;
+      *token_out = slot;
+      return ODEHIP_OK;
+    }
     if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
     return ODEHIP_OK;
   }
@@ -603,111 +773,59 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   fa.off_x2 = (long long)(1 * BL.st);
 
   ODEHIP_CHECK_HIP(hipMemsetAsync(psync, 0, persist_sync_bytes(batch), stream));   // first attempt's flag area; the controller zeroes it for the next
-  // ---- attempted steps; the host runs at most RUN_AHEAD attempts ahead of the device
-  // one attempt queued behind the running one keeps the GPU busy (enqueue ~0.1 ms < attempt ~0.4 ms).  Exact-global mode
-  // enqueues a collective per attempt, so every rank must enqueue the same number of attempts: no run-ahead there.
-  const int RUN_AHEAD = global_norm ? 0 : 1;
-  double t_progress = now_s();
-  int enq = 0, seen = 0;
-  for (;;) {
-    // the six evaluations of an attempt are conv launches only: one persistent launch (the same table for every attempt: the
-    // step size is read through h_ptr, the queued-behind-`done` case through the skip word)
-    PersistScope persist;
-    if ((rc = persist.begin(f, nullptr, 6 * f->n_convs)) != ODEHIP_OK) return rc;
-    for (int s = 2; s <= 7; ++s) {  // k_s = f(x_s); fused: x_{s+1} = y + h*sum beta_{s+1,j} k_j   (s = 7: error norm)
-      memset(&c, 0, sizeof(c));
-      c.k_scale = ksc;
-      c.order = all_64(f);   // 64-channel stacks: the adaptive walk (stage sums formed ahead of the matrix work), same bits per layer
-      c.y = y;
-      c.h_ptr = &state->h;
-      c.n_prev = s - 1;
-      for (int j = 0; j < s - 1; ++j) c.k_prev[j] = k[j];
-      c.k_out = k[s - 1];
-      if (s <= 6) {
-        for (int j = 0; j < s; ++j) c.c1[j] = (float)dp5::kBeta[s - 1][j];
-        c.out1 = saving ? s_xin(s) : (s < 6 ? xs : y1);  // x7 = y1 (c_sol equals the last beta row)
-      } else {
-        for (int j = 0; j < 7; ++j) c.ce[j] = (float)dp5::kCErr[j];
-        c.err_y1 = saving ? s_xin(6) : y1;
-        c.err_partials = part0;
-        c.rtol = rtol;
-        c.atol = atol;
-      }
-      if (saving) {   // evaluation (slot, s - 1): input and hidden activations live in the slot the device picks
-        ODEHIP_REQUIRE(persist.recording(), "odeint_dopri5: the persistent walk became unavailable during a saving forward");
-        float* hid_s[ODEHIP_MAX_LAYERS];
-        for (int l = 0; l < BL.NH; ++l) hid_s[l] = s_hid(s - 1, l);
-        rc = enqueue_f_saving(f, s_xin(s - 1), batch, hid_s, ping, pong, &c, nullptr, skip, stream);
-      } else {
-        rc = enqueue_f(f, s < 7 ? xs : y1, batch, ping, pong, &c, nullptr, skip, stream);
-      }
-      if (rc != ODEHIP_OK) return rc;
-    }
-    if (saving) persist.set_device_steering(nullptr, reloc);
-    if ((rc = persist.finish(nullptr, nullptr, nullptr, batch, psync, f->ks, stream, /*sync_is_zero=*/true)) != ODEHIP_OK) return rc;
-    if (global_norm) {
-      const float* arr[1] = {part0};
-      const int lens[1] = {n_conv_partials};
-      if ((rc = reduce_sums(1, arr, lens, nullptr)) != ODEHIP_OK) return rc;
-    }
-    hipLaunchKernelGGL(controller_kernel, dim3(1), dim3(256), 0, stream, state, global_norm ? g_reduce_buf : part0, t_dev, g_mailbox, psync,
-                       (int)(persist_sync_bytes(batch) / 4));
-    hipLaunchKernelGGL(finish_kernel, dim3(1024), dim3(256), 0, stream, fa, n4, (float)dp5::kCMid[0], (float)dp5::kCMid[2],
-                       (float)dp5::kCMid[3], (float)dp5::kCMid[4], (float)dp5::kCMid[5], (float)dp5::kCMid[6]);
-    ODEHIP_CHECK_HIP(hipGetLastError());
-    ++enq;
-    // bound the run-ahead; leave as soon as the controller reports done
-    while (!g_mailbox->done && g_mailbox->steps_done + RUN_AHEAD < enq) {
-      if (g_mailbox->steps_done != seen) {   // the limit is on time WITHOUT progress, not on the whole integration
-        seen = g_mailbox->steps_done;
-        t_progress = now_s();
-      }
-      if (now_s() - t_progress > 120.0) {
-        set_error("odeint_dopri5: no progress from the device for 120 s (steps done %d of %d enqueued)", g_mailbox->steps_done, enq);
-        return ODEHIP_EHIP;
-      }
-    }
-    if (g_mailbox->done) break;
+  // ---- attempted steps
+  cx.f = *f;
+  cx.n_times = n_times; cx.batch = batch; cx.n_conv_partials = n_conv_partials;
+  cx.rtol = rtol; cx.atol = atol; cx.ksc = ksc;
+  cx.stream = stream;
+  cx.state = state; cx.t_dev = t_dev; cx.part0 = part0; cx.ping = ping; cx.pong = pong; cx.xs = xs; cx.y = y; cx.y1 = y1;
+  for (int i = 0; i < 7; ++i) cx.k[i] = k[i];
+  cx.psync = psync; cx.reloc = reloc;
+  cx.saving = saving; cx.global_norm = global_norm;
+  cx.bl_st = BL.st; cx.bl_hid = BL.hid; cx.bl_nh = BL.NH;
+  cx.fa = fa;
+  cx.n4 = n4;
+  if (async_attempts > 0) {
+    // ASYNCHRONOUS start: a fixed number of attempts is enqueued (those behind `done` return at once) and the call returns without
+    // waiting for the device; odehip_odeint_dopri5_collect() reads the outcome later and carries on should the solve need more
+    for (int i = 0; i < async_attempts; ++i)
+      if ((rc = d5_attempt(cx)) != ODEHIP_OK) return rc;
+    cx.in_use = true;
+    *token_out = slot;
+    return ODEHIP_OK;
   }
-  // attempts enqueued after `done` do nothing (skip flag); wait for the last controller so the mailbox is final
-  while (g_mailbox->steps_done < enq) {
-    if (g_mailbox->steps_done != seen) {
-      seen = g_mailbox->steps_done;
-      t_progress = now_s();
-    }
-    if (now_s() - t_progress > 120.0) {
-      set_error("odeint_dopri5: device did not drain");
-      return ODEHIP_EHIP;
-    }
+  if ((rc = d5_run_to_done(cx)) != ODEHIP_OK) return rc;
+  return d5_collect(cx, stats_host, accepted_host, accepted_cap, saved_out);
+}
+
+// ---- the asynchronous pair (ABI 8).  start = odehip_odeint_dopri5_saving's arguments (max_accept = 0: nothing is kept) + how many
+// attempted steps to enqueue before returning; nothing is waited for and no outcome is reported.  collect(token) waits for the
+// device (normally long done), enqueues further attempts if the solve is not finished, and returns what the synchronous call
+// returns (status code, stats, accepted-step log, saved flag).  Everything the start call was given (workspace, out, z0) must stay
+// untouched until collect; at most four solves may be pending.
+extern "C" int odehip_odeint_dopri5_start(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
+                                          float rtol, float atol, double first_step, int max_steps, float* out_nchw, int max_accept,
+                                          int attempts, int* token_out, void* workspace, size_t workspace_bytes, void* stream_) {
+  ODEHIP_REQUIRE(token_out && attempts > 0, "odeint_dopri5_start: token_out is required and attempts must be positive");
+  *token_out = -1;
+  ODEHIP_REQUIRE(f && workspace_bytes >= (max_accept > 0 ? odehip_dopri5_saving_workspace_bytes(f, batch, n_times, max_accept)
+                                                           : odehip_dopri5_workspace_bytes(f, batch, n_times)),
+                 "odeint_dopri5_start: workspace too small");
+  int saved_dummy = 0;
+  return dopri5_forward(f, z0_nchw, t_host, n_times, batch, rtol, atol, first_step, max_steps, 0, out_nchw, nullptr, nullptr, 0, workspace,
+                        workspace_bytes, stream_, max_accept, &saved_dummy, attempts, token_out);
+}
+
+extern "C" int odehip_odeint_dopri5_collect(int token, int* stats_host, double* accepted_host, int accepted_cap, int* saved_out) {
+  ODEHIP_REQUIRE(token >= 0 && token < kD5Slots && g_d5[token].in_use, "odeint_dopri5_collect: no pending solve with token %d", token);
+  D5Ctx& cx = g_d5[token];
+  cx.in_use = false;   // whatever happens below, the slot is free again
+  if (saved_out) *saved_out = 0;
+  if (cx.n_times == 1) {
+    if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
+    return ODEHIP_OK;
   }
-  // the device has finished every attempt of this call: a persistent launch that gave up a wait is known NOW
-  if (const unsigned code = persist_error(true)) {
-    set_error("odeint_dopri5: a persistent launch gave up waiting for a partner workgroup (code %u); the trajectory is invalid.  "
-              "Persistent launches are now disabled for this process", code);
-    return ODEHIP_EHIP;
-  }
-  if (saved_out) *saved_out = saving && g_mailbox->save_ok && g_mailbox->status == 0;
-  if (stats_host) {
-    stats_host[0] = g_mailbox->nfe;
-    stats_host[1] = g_mailbox->n_accept;
-    stats_host[2] = g_mailbox->n_reject;
-    stats_host[3] = enq;
-  }
-  if (accepted_host) {  // (t0, dt) pairs; the caller sees from stats_host[1] > accepted_cap that the log is incomplete
-    int n = g_mailbox->n_accept < kLogCap ? g_mailbox->n_accept : kLogCap;
-    if (n > accepted_cap) n = accepted_cap;
-    for (int i = 0; i < n; ++i) {
-      accepted_host[2 * i] = g_mailbox->log[i][0];
-      accepted_host[2 * i + 1] = g_mailbox->log[i][1];
-    }
-  }
-  if (g_mailbox->status == ODEHIP_ENAN) {
-    set_error("odeint_dopri5: non-finite error ratio (non-finite values in state `y`)");
-    return ODEHIP_ENAN;
-  }
-  if (g_mailbox->status == ODEHIP_ENOTCONV) {
-    set_error("odeint_dopri5: underflow in dt or max_num_steps exceeded");
-    return ODEHIP_ENOTCONV;
-  }
-  return ODEHIP_OK;
+  int rc = d5_run_to_done(cx);
+  if (rc != ODEHIP_OK) return rc;
+  return d5_collect(cx, stats_host, accepted_host, accepted_cap, saved_out);
 }

@@ -477,6 +477,156 @@ def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=
 
 _dopri5_save_slots = 8   # slots of a saving forward's workspace; doubled (up to 64) after a forward that accepted more steps
 
+# ---- asynchronous dopri5 (include/odecgru_hip.h: odehip_odeint_dopri5_start / _collect) ------------------------------------------
+# The synchronous entry points return when the device-side controller has reported completion, so the host cannot enqueue what comes
+# BEHIND the solver meanwhile: in a whole training step (encoder -> solver -> decoder -> loss -> backward, ~600 launches) the device
+# then idles while the backward pass is being enqueued (ODEConvGRU, B=64, dopri5: 20.9 ms per step against 12.1 ms of device work).
+# With set_async_dopri5(True) a solve only ENQUEUES a few attempted steps and returns; its outcome (step counts, accepted-step log,
+# whether activations were kept -- and any error: dt underflow, max_num_steps, non-finite state) is read when it is needed: at the
+# backward pass, at the first look into ode_rl_amd.last_stats, or at the next dopri5 call.  Off by default: torchdiffeq raises such
+# errors from odeint() itself, and so does the synchronous path.
+_async_dopri5 = os.environ.get("ODEHIP_DOPRI5_ASYNC") == "1"
+_async_attempts = 4      # attempted steps enqueued up front; follows what the previous solve needed
+_pending_solves = []     # PendingDopri5 objects not collected yet
+
+
+def set_async_dopri5(on=True):
+    """Switch the asynchronous dopri5 forward on / off (see above); returns the previous setting."""
+    global _async_dopri5
+    was = _async_dopri5
+    if not on:
+        collect_pending_solves()
+    _async_dopri5 = bool(on)
+    return was
+
+
+def collect_pending_solves():
+    """Wait for every dopri5 solve started asynchronously and surface its error, if any."""
+    while _pending_solves:
+        _pending_solves[0].collect()
+
+
+class PendingDopri5:
+    """A dopri5 solve that has been enqueued but whose outcome has not been read yet."""
+
+    def __init__(self, token, keep, slots, ws):
+        self.token, self._keep, self.slots, self.ws = token, keep, slots, ws
+        self._result = None
+        _pending_solves.append(self)
+
+    def collect(self):
+        """(stats dict, saved) -- saved = (workspace, slots) if the activations of the accepted steps were kept, else None."""
+        global _dopri5_save_slots, _async_attempts
+        if self._result is None:
+            if self in _pending_solves:
+                _pending_solves.remove(self)
+            stats = (ctypes.c_int * 4)()
+            log = (ctypes.c_double * (2 * LOG_CAP))()
+            saved = ctypes.c_int(0)
+            lib = _lib.load()
+            try:
+                _lib.check(lib.odehip_odeint_dopri5_collect(int(self.token), stats, log, LOG_CAP, ctypes.byref(saved)))
+            finally:
+                self._keep = None
+            k = min(int(stats[1]), LOG_CAP)
+            if self.slots and int(stats[1]) > self.slots:
+                _dopri5_save_slots = min(64, max(2 * self.slots, int(stats[1]) + 2))
+            _async_attempts = max(2, min(16, int(stats[1]) + int(stats[2]) + 1))
+            st = {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3],
+                  "accepted": [(log[2 * i], log[2 * i + 1]) for i in range(k)], "saved": bool(saved.value)}
+            self._result = (st, (self.ws, self.slots) if saved.value else None)
+            self.ws = None
+        return self._result
+
+
+class LazyStats(dict):
+    """`ode_rl_amd.last_stats`: a dict that, after an asynchronous solve, fills itself on first access."""
+    _pending = None
+
+    def _bind(self, pending):
+        dict.clear(self)
+        self._pending = pending
+
+    def _resolve(self):
+        p, self._pending = self._pending, None
+        if p is not None:
+            dict.update(self, p.collect()[0])
+
+    def clear(self):
+        self._pending = None
+        dict.clear(self)
+
+    def __getitem__(self, k):
+        self._resolve()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._resolve()
+        return dict.get(self, k, d)
+
+    def __iter__(self):
+        self._resolve()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._resolve()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._resolve()
+        return dict.__contains__(self, k)
+
+    def keys(self):
+        self._resolve()
+        return dict.keys(self)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def copy(self):
+        self._resolve()
+        return dict(dict.items(self))
+
+    def __eq__(self, other):
+        self._resolve()
+        return dict.__eq__(self, other)
+
+    def __repr__(self):
+        self._resolve()
+        return dict.__repr__(self)
+
+
+def odeint_dopri5_start(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, save=False):
+    """Asynchronous dopri5 forward: returns (out, PendingDopri5) at once.  save=True keeps the activations of the accepted steps
+    (as odeint_dopri5_saving does) in a private workspace held by the pending object."""
+    collect_pending_solves()      # one solve in flight per process: the shared workspaces and the library's slots are free again
+    require_device_tensor(z0, "y0")
+    desc = stack.refresh()
+    z0 = z0.contiguous()
+    b, c = z0.shape[0], z0.shape[1]
+    if z0.dim() != 4 or tuple(z0.shape[2:]) != (16, 16) or c != desc.channels[0]:
+        raise ValueError(f"y0 must be (B,{desc.channels[0]},16,16) (got {tuple(z0.shape)})")
+    t64 = [float(v) for v in t.detach().to("cpu", torch.float64).tolist()]
+    n = len(t64)
+    lib = _lib.load()
+    slots = _dopri5_save_slots if save and os.environ.get("ODEHIP_DOPRI5_SAVE") != "0" else 0
+    if slots:
+        ws = alloc_workspace(lib.odehip_dopri5_saving_workspace_bytes(ctypes.byref(desc), b, n, slots), z0.device)
+    else:
+        ws = workspace(("dopri5", b, n, tuple(desc.channels)), lib.odehip_dopri5_workspace_bytes(ctypes.byref(desc), b, n), z0.device)
+    out = torch.empty((n, b, c, 16, 16), dtype=torch.float32, device=z0.device)
+    tarr = (ctypes.c_double * n)(*t64)
+    token = ctypes.c_int(-1)
+    _lib.check(lib.odehip_odeint_dopri5_start(ctypes.byref(desc), _ptr(z0), tarr, n, b, float(rtol), float(atol), float(first_step or 0.0),
+                                              int(max_steps), _ptr(out), int(slots), int(_async_attempts), ctypes.byref(token), _ptr(ws),
+                                              ws.numel(), _stream()))
+    return out, PendingDopri5(token.value, (z0, out, ws), slots, ws if slots else None)
+
 
 def odeint_dopri5_saving(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
     """The forward of a dopri5 TRAINING step: odeint_dopri5 that also keeps the stage inputs and hidden activations of every accepted
@@ -484,6 +634,9 @@ def odeint_dopri5_saving(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
     (workspace, max_accept), or None when nothing was kept (other stacks than 64-channel fp32, persistent walk off, more accepted
     steps than slots): the caller then takes odeint_dopri5_backward."""
     global _dopri5_save_slots
+    if _async_dopri5:   # enqueue only: stats and `saved` are read later (LazyStats / PendingDopri5.collect())
+        out, pending = odeint_dopri5_start(stack, z0, t, rtol, atol, first_step=first_step, max_steps=max_steps, save=True)
+        return out, pending, pending
     if os.environ.get("ODEHIP_DOPRI5_SAVE") == "0":   # A/B switch: always re-integrate in the backward pass
         out, st = odeint_dopri5(stack, z0, t, rtol, atol, first_step=first_step, max_steps=max_steps)
         st["saved"] = False

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import hip_ops
 
 FIXED_GRID = ("euler", "midpoint", "rk4")
-last_stats = {}  # nfe / n_accept / n_reject of the most recent dopri5 call (instrumentation)
+last_stats = hip_ops.LazyStats()  # nfe / n_accept / n_reject of the most recent dopri5 call (instrumentation; fills itself after an asynchronous solve)
 
 
 def _host_times(t):
@@ -88,6 +88,11 @@ def odeint_forward(func, y0, t, rtol, atol, method, options=None):
     unknown = set(options) - {"first_step", "max_num_steps"}
     if unknown:
         raise ValueError(f"odeint(HIP): unsupported dopri5 options {sorted(unknown)}")
+    if hip_ops._async_dopri5 and not negate:   # enqueue only; the stats are read when somebody looks at them
+        out, pending = hip_ops.odeint_dopri5_start(stack, y0, th, rtol, atol, first_step=float(options.get("first_step") or 0.0),
+                                                   max_steps=int(options.get("max_num_steps") or 0))
+        last_stats._bind(pending)
+        return out
     out, stats = hip_ops.odeint_dopri5(stack, y0, th, rtol, atol, first_step=float(options.get("first_step") or 0.0),
                                        max_steps=int(options.get("max_num_steps") or 0), negate=negate)
     last_stats.clear()

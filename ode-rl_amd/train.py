@@ -7,17 +7,25 @@ import pickle
 import torch
 
 
-def train_batch(model, batch_dict, optimizer):
-    """One optimisation step.  batch_dict: 'observed_data' (B,T_in,C,H,W) and 'data_to_predict' (B,T_out,C,H,W) in
+def train_batch(model, batch_dict, optimizer, async_solver=True):
+    """One optimisation step.  async_solver: a dopri5 solve inside the model only enqueues its attempted steps and the backward
+    pass collects its outcome (ode_rl_amd.set_async_dopri5): the host goes on enqueueing decoder, loss and backward while the
+    device still integrates; a solver error (dt underflow, non-finite state) then surfaces at loss.backward().  batch_dict: 'observed_data' (B,T_in,C,H,W) and 'data_to_predict' (B,T_out,C,H,W) in
     [-0.5, 0.5] as the reference's loaders deliver them, plus 'observed_tp' / 'tp_to_predict'.  Returns
     (pred * 255, truth * 255, loss tensor, loss_dict) -- the loss stays on the device (no .item() synchronisation here)."""
     dev = next(model.parameters()).device
     inp = batch_dict["observed_data"].to(dev) + 0.5          # train_test.py:180: [-0.5, 0.5] -> [0, 1]
     out = batch_dict["data_to_predict"].to(dev) + 0.5
-    optimizer.zero_grad(set_to_none=False)
-    pred = model.get_prediction(inp, batch_dict=batch_dict)
-    loss = model.get_loss(pred, out)
-    loss.backward()
+    from . import hip_ops
+    was = hip_ops.set_async_dopri5(True) if async_solver else hip_ops._async_dopri5
+    try:
+        optimizer.zero_grad(set_to_none=False)
+        pred = model.get_prediction(inp, batch_dict=batch_dict)
+        loss = model.get_loss(pred, out)
+        loss.backward()
+    finally:
+        if async_solver:
+            hip_ops.set_async_dopri5(was)
     optimizer.step()
     return pred.detach() * 255.0, out * 255.0, loss.detach(), {"Per Step Loss": loss.detach()}
 

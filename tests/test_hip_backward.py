@@ -413,3 +413,68 @@ def test_dopri5_saving_forward_equals_reintegration(cuda, first_step, batch):
             os.environ.pop("ODEHIP_DOPRI5_SAVE", None)
         else:
             os.environ["ODEHIP_DOPRI5_SAVE"] = old
+
+
+def test_async_dopri5_forward_matches_the_synchronous_one(cuda):
+    """Round 3: with ode_rl_amd.set_async_dopri5(True) a dopri5 solve only enqueues its attempted steps; the outcome is read at the
+    backward pass / at the first look into last_stats / at the next solve.  Same trajectory, same gradients (bit for bit), same
+    stats as the synchronous call -- also when the solve needs MORE attempts than were enqueued up front (forced rejections) --
+    and an error (max_num_steps) surfaces when the outcome is collected."""
+    import ode_rl_amd
+    from ode_rl_amd import hip_ops
+    f, _ = _setup(3)
+    with torch.no_grad():
+        f.gradient_net[8].weight.mul_(12.0)
+    f = f.to(cuda)
+    g = torch.Generator().manual_seed(41)
+    z0 = (torch.randn(3, 64, 16, 16, generator=g) * 0.5).to(cuda)
+    t = torch.tensor([0.0, 1.0, 2.5, 4.0], dtype=torch.float64)
+    gout = torch.randn(4, 3, 64, 16, 16, generator=g).to(cuda)
+
+    def run(adjoint=False):
+        f.zero_grad()
+        z = z0.clone().requires_grad_(True)
+        if adjoint:
+            sol = ode_rl_amd.odeint_adjoint(f, z, t, rtol=1e-4, atol=1e-5, method="dopri5", options={"first_step": 3.0},
+                                            adjoint_options={"norm": "seminorm"})
+        else:
+            sol = ode_rl_amd.odeint(f, z, t, rtol=1e-4, atol=1e-5, method="dopri5", options={"first_step": 3.0})
+        sol.backward(gout)
+        st = dict(ode_rl_amd.last_stats)
+        return sol.detach().clone(), z.grad.clone(), [p.grad.clone() for p in f.parameters()], st
+
+    ref = run()
+    ref_adj = run(adjoint=True)
+    with torch.no_grad():
+        ref_inf = ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5")
+        ref_inf_stats = dict(ode_rl_amd.last_stats)
+    was = ode_rl_amd.set_async_dopri5(True)
+    attempts = hip_ops._async_attempts
+    try:
+        hip_ops._async_attempts = 2          # fewer than the solve needs (2 rejected + 3 accepted): collect() must carry on
+        got = run()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
+        for k in ("nfe", "n_accept", "n_reject", "accepted"):
+            assert got[3][k] == ref[3][k], k
+        assert ref[3]["n_reject"] >= 2 and ref[3]["n_accept"] >= 3
+        assert hip_ops._async_attempts >= 5  # the next solve enqueues what this one needed
+        got2 = run()                         # ... and then needs no second round
+        assert torch.equal(got2[1], ref[1])
+        gadj = run(adjoint=True)
+        assert torch.equal(gadj[0], ref_adj[0]) and torch.equal(gadj[1], ref_adj[1])
+        with torch.no_grad():
+            inf = ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5")
+            assert len(hip_ops._pending_solves) == 1          # nothing has been waited for yet
+            assert ode_rl_amd.last_stats["nfe"] == ref_inf_stats["nfe"] and not hip_ops._pending_solves
+        assert torch.equal(inf, ref_inf)
+        # an error is reported when the outcome is collected, as the exception the synchronous call raises
+        with torch.no_grad():
+            ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5", options={"first_step": 3.0, "max_num_steps": 2})
+            with pytest.raises(AssertionError):
+                ode_rl_amd.last_stats["nfe"]
+            again = ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5")     # the library is usable afterwards
+            ode_rl_amd.collect_pending_solves()
+        assert torch.equal(again, ref_inf)
+    finally:
+        hip_ops._async_attempts = attempts
+        ode_rl_amd.set_async_dopri5(was)

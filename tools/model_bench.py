@@ -20,6 +20,7 @@ def main():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="compute dtype of the hot-path convs")
     p.add_argument("--only", default="all", choices=["all", "train"], help="'train': time the training step alone (profiling)")
+    p.add_argument("--sync-solver", action="store_true", help="dopri5: the synchronous forward (the host waits for the controller inside the model's forward)")
     p.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen search solvers for the convs either side of the path")
     a = p.parse_args()
     torch.backends.cudnn.benchmark = a.miopen_find
@@ -27,6 +28,7 @@ def main():
     from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
     if a.dtype == "bf16":
         ode_rl_amd.set_compute_dtype("bf16")
+    ode_rl_amd.set_async_dopri5(not a.sync_solver)   # a training harness: the solver's outcome is only needed at the backward pass
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     opt = argparse.Namespace(resolution=64, n_downs=2, conv_encoder_out_ch=64, in_channels=1, n_ode_layers=3,
@@ -61,7 +63,7 @@ def main():
         loss.backward()
         optim.step()
 
-    res = {"batch": a.batch, "frames_in": T, "frames_out": T, "method": a.method, "dtype": a.dtype}
+    res = {"batch": a.batch, "frames_in": T, "frames_out": T, "method": a.method, "dtype": a.dtype, "async_dopri5": not a.sync_solver}
     if a.only == "train":
         res["train_step_ms"] = timed(train, a.steps)
         print(json.dumps(res), flush=True)
