@@ -313,6 +313,7 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
   const size_t st_b = (size_t)batch * L.C * kPix * 4;
   int rc;
 
+  const int n_pps = persist_partials_per_sample(batch);   // (before the scope: it takes the library's lock)
   PersistScope persist;
   if ((rc = persist.begin(f, f_dgrad, 2 + 15 + 14 + 62)) != ODEHIP_OK) return rc;
   if (!persist.recording()) return ODEHIP_OK;   // no persistent walk on this device / switched off: the host loop takes the call
@@ -330,7 +331,7 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
     ky[i] = L.p(ws, L.off_ky + (size_t)i * L.st);
     ka[i] = L.p(ws, L.off_ka + (size_t)i * L.st);
   }
-  const int part_stride = L.n_part > 256 ? L.n_part : 256;
+  const int part_stride = L.part_stride();
 
   rc = odehip_nchw_to_q4(y_traj_nchw, L.p(ws, L.off_y), n_times * batch, L.C, stream);
   if (rc != ODEHIP_OK) return rc;
@@ -556,7 +557,7 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
   init.rtol = rtol;
   init.atol = atol;
   init.n_times = n_times;
-  init.n_part = L.n_part;
+  init.n_part = batch * n_pps;   // partials per array: 16 per sample on the 4-workgroup walk, 64 on the sixteen-workgroup one
   init.max_slots = L.max_slots;
   init.n_layers = NL;
   init.nh = NH;

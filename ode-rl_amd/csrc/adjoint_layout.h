@@ -21,7 +21,7 @@ struct AdjLayout {
     size_t o = 0;
     auto take = [&](size_t b) { size_t r = o; o += al256(b); return r; };
     off_h = take(256);
-    off_part = take(8 * (size_t)(n_part > 256 ? n_part : 256) * 4);
+    off_part = take(8 * (size_t)part_stride() * 4);
     off_sums = take(256);
     off_ping = take(hid);
     off_pong = take(hid);
@@ -50,7 +50,9 @@ struct AdjLayout {
   float* gp(const void* ws, int slot, int s, int l) const {
     return p(ws, off_slots + (size_t)slot * slot_bytes + 7 * st + 7 * (size_t)NH * hid + ((size_t)s * (NH + 1) + l) * hid);
   }
-  float* part(const void* ws, int j) const { return p(ws, off_part + (size_t)j * (n_part > 256 ? n_part : 256) * 4); }
+  // floats per partial array: the per-layer kernels write n_part, the sixteen-workgroup walk 64 per sample (batch <= 16)
+  int part_stride() const { return n_part > 1024 ? n_part : 1024; }
+  float* part(const void* ws, int j) const { return p(ws, off_part + (size_t)j * part_stride() * 4); }
 };
 
 

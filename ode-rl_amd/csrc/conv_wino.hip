@@ -1048,13 +1048,15 @@ struct Hook16 {
   bool fence, first;
   float* nchw_base;
   int sleep6;
+  const unsigned long long* reloc;   // relocation bases of an adaptive table (rel()), or null
+  unsigned wait_target;              // target, or target - 1 for a row that does not depend on the row in front of it (dep_back)
 };
 
 __device__ __forceinline__ void wait_done16(const Hook16& hk, int lo_word, int hi_word) {
   int n = 0;
   const int lane = threadIdx.x & 63;
   const bool mine = lane >= lo_word && lane < hi_word;
-  while (!__all(!mine || __hip_atomic_load(hk.done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.target)) {
+  while (!__all(!mine || __hip_atomic_load(hk.done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hk.wait_target)) {
     __builtin_amdgcn_s_sleep(1);
     if ((++n & 1023) == 0) {
       if (__hip_atomic_load(hk.abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) break;
@@ -1140,7 +1142,8 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
     // DMA order per wave: U_0 (4) | raw_0 (2) | raw_1 (2) | then per iteration c: U_{c+1} (4) | raw_{c+2} (2)
     issue_u(0, 0);
     if (!hk.first) {
-      for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
+      if (hk.wait_target == hk.target)   // (a row with a relaxed dependency has nothing to sleep for)
+        for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
       const int lo = rq > 0 ? (rq - 1) * 16 : 0, hi = rq < 3 ? (rq + 2) * 16 : 64;
       wait_done16(hk, lo, hi);
     }
@@ -1181,9 +1184,21 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias4 = *(const f32x4*)(a.bias + Q * 4);
   // epilogue operands fetched now (this lane's own earlier outputs, as in the 4-workgroup walk)
-  const int e_combine = a.combine;
+  const unsigned long long* const rl = hk.reloc;
+  typedef const __attribute__((address_space(4))) float ConstF16;
+  // an order-1 stage combine (the adaptive solver's tables) is reduced to y, two partial sums and y1 here, a reverse-sweep row with
+  // up to two constant-coefficient targets to its (srcA, srcB) pairs -- the adaptive walk's scheme (wino_layer<..., ADAPT>), one quad
+  // per lane; pointers may be relocatable
+  const bool adapt1 = a.combine == 1 && a.cmb.order == 1 && !(a.cmb.err_partials && (a.cmb.out2 || a.dbg));
+  const bool adapt3 = a.combine == 3 && a.bwd.n_targets <= 2 && !a.bwd.h_ptr;
+  const int e_combine = adapt1 ? 6 : (adapt3 ? 7 : a.combine);
   const int e_relu = a.relu;
-  float* const e_dst = a.dst;
+  float* const e_dst = rel(rl, a.dst);
+  f32x4 d_y1 = {0.f, 0.f, 0.f, 0.f}, d_sa = {0.f, 0.f, 0.f, 0.f}, d_sb = {0.f, 0.f, 0.f, 0.f};
+  float d_cB = 0.0f, d_rtol = 0.0f, d_atol = 0.0f, d_t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float* d_o[2] = {nullptr, nullptr};
+  bool d_err = false, d_f[4] = {false, false, false, false};
+  float* d_part = nullptr;
   int e_np = 0;
   float* e_kout = nullptr;
   float* e_out1 = nullptr;
@@ -1213,11 +1228,62 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
     }
   } else if (e_combine == 2) {   // ReLU-mask layer of a reverse sweep: the mask value is fetched now
     const BwdArgs& w = a.bwd;
-    typedef const __attribute__((address_space(4))) float ConstF;
-    const float hb = a.h_by_value ? a.cmb.atol : (w.h_ptr ? *(ConstF*)w.h_ptr : 0.0f);
+    const float hb = a.h_by_value ? a.cmb.atol : (w.h_ptr ? *(ConstF16*)w.h_ptr : 0.0f);
     e_ks = w.sc_c + w.sc_h * hb;
     e_y = w.mask_src != nullptr;
-    if (e_y) e_yv = *(const f32x4*)(w.mask_src + off);
+    if (e_y) e_yv = *(const f32x4*)(rel(rl, w.mask_src) + off);
+  } else if (e_combine == 6) {   // order-1 stage combine: the sums over the earlier stages (combine1_prev's fma sequence)
+    const CombineArgs& m = a.cmb;
+    e_np = m.n_prev;
+    e_h = a.h_by_value ? m.atol : (m.h_ptr ? *(ConstF16*)m.h_ptr : 1.0f);
+    e_ks = m.k_scale;
+    d_err = m.err_partials != nullptr;
+    d_part = m.err_partials;
+    e_y = m.y != nullptr;
+    e_c1c = m.c1[e_np];
+    d_cB = d_err ? m.ce[e_np] : m.c2[e_np];
+    d_rtol = m.rtol; d_atol = m.atol;
+    e_kout = rel(rl, m.k_out);
+    e_out1 = rel(rl, m.out1);
+    e_out2 = rel(rl, m.out2);
+    e_nchw = m.out2_nchw;
+    const bool needB = d_err || e_out2 || e_nchw;
+    if (e_y) {
+      e_yv = *(const f32x4*)(rel(rl, m.y) + off);
+      if (d_err) d_y1 = *(const f32x4*)(rel(rl, m.err_y1) + off);
+      const float* kp[ODEHIP_MAX_STAGES - 1];
+      float cA[ODEHIP_MAX_STAGES - 1], cB[ODEHIP_MAX_STAGES - 1];
+#pragma unroll
+      for (int j = 0; j < ODEHIP_MAX_STAGES - 1; ++j) {
+        kp[j] = j < e_np ? rel(rl, m.k_prev[j]) : nullptr;
+        cA[j] = m.c1[j];
+        cB[j] = d_err ? m.ce[j] : m.c2[j];
+      }
+#pragma unroll
+      for (int j = 0; j < ODEHIP_MAX_STAGES - 1; ++j)
+        if (j < e_np) {
+          const f32x4 kv = *(const f32x4*)(kp[j] + off);
+          d_sa = fma4(kv, cA[j], d_sa);
+          if (needB) d_sb = fma4(kv, cB[j], d_sb);
+        }
+    }
+  } else if (e_combine == 7) {   // reverse-sweep targets held in registers
+    const BwdArgs& w = a.bwd;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < w.n_targets) {
+        const BwdTarget& T = w.tgt[t];
+        d_o[t] = rel(rl, T.out);
+        d_t[3 * t] = T.g_c; d_t[3 * t + 1] = T.a_c; d_t[3 * t + 2] = T.b_c;
+        d_f[2 * t] = T.srcA != nullptr; d_f[2 * t + 1] = T.srcB != nullptr;
+        if (t == 0) {
+          if (d_f[0]) e_yv = *(const f32x4*)(rel(rl, T.srcA) + off);
+          if (d_f[1]) d_y1 = *(const f32x4*)(rel(rl, T.srcB) + off);
+        } else {
+          if (d_f[2]) d_sa = *(const f32x4*)(rel(rl, T.srcA) + off);
+          if (d_f[3]) d_sb = *(const f32x4*)(rel(rl, T.srcB) + off);
+        }
+      }
   }
 #pragma unroll
   for (int c = 0; c < nchunk; ++c) {
@@ -1273,6 +1339,41 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
   } else if (e_combine == 3) {   // reverse-sweep targets: the shared epilogue, read from the table
     float esum = 0.0f;
     emit_quad<false>(a, b, Q, P, val, esum);
+  } else if (e_combine == 6) {
+    const f32x4 kc = val * e_ks;
+    if (e_kout) *(f32x4*)(e_kout + off) = kc;
+    if (e_y) {
+      if (e_out1) *(f32x4*)(e_out1 + off) = fma4(fma4(kc, e_c1c, d_sa), e_h, e_yv);
+      if (d_err) {
+        // this wave's partial of the error norm: 64 partials per sample here (16 workgroups x 4 waves), added by the controller in a
+        // fixed order -- not the per-layer kernels' order, so batches up to 16 agree with one launch per layer to round-off of the
+        // NORM only (every stored value is still bit-identical)
+        float esum = combine1_err(fma4(kc, d_cB, d_sb), e_h, e_yv, d_y1, d_rtol, d_atol, 0.0f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+        if (lane == 0) d_part[(b * 16 + rq * 4 + cq) * 4 + wave] = esum;
+      } else if (e_out2 || e_nchw) {
+        const f32x4 o2 = fma4(fma4(kc, d_cB, d_sb), e_h, e_yv);
+        if (e_out2) *(f32x4*)(e_out2 + off) = o2;
+        if (e_nchw) {
+          float* o = e_nchw + ((size_t)b * 64 + Q * 4) * kPix + P;
+          o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+        }
+      }
+    }
+  } else if (e_combine == 7) {
+    if (d_o[0]) {
+      f32x4 o = val * d_t[0];
+      if (d_f[0]) o = fma4(e_yv, d_t[1], o);
+      if (d_f[1]) o = fma4(d_y1, d_t[2], o);
+      *(f32x4*)(d_o[0] + off) = o;
+    }
+    if (d_o[1]) {
+      f32x4 o = val * d_t[3];
+      if (d_f[2]) o = fma4(d_sa, d_t[4], o);
+      if (d_f[3]) o = fma4(d_sb, d_t[5], o);
+      *(f32x4*)(d_o[1] + off) = o;
+    }
   } else {
     const f32x4 kc = val * e_ks;
     if (e_kout) *(f32x4*)(e_kout + off) = kc;
@@ -1297,6 +1398,52 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
         }
       }
     }
+  }
+  wait_vmcnt<0>();
+  if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(hk.done + (rq * 4 + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// elementwise / norm rows (ConvArgs::combine == 4 / 5) in the sixteen-workgroup layout: a lane's one quad (see ew_row)
+__device__ __forceinline__ void ew_row16(const ConvArgs& a, int b, int cq, int rq, const Hook16& hk) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave >= 4) return;
+  typedef const __attribute__((address_space(4))) float ConstF;
+  const CombineArgs& m = a.cmb;
+  const unsigned long long* const rl = hk.reloc;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int Q = cq * 4 + kq, oa = wave >> 1, ob = wave & 1, oty = i16 >> 3, otx = i16 & 7;
+  const int P = (rq * 4 + 2 * oty + oa) * 16 + 2 * otx + ob;
+  const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+  const float* const yp = rel(rl, m.y);
+  if (a.combine == 5) {
+    f32x4 d = *(const f32x4*)(rel(rl, m.k_prev[0]) + off);
+    const f32x4 yv = *(const f32x4*)(yp + off);
+    if (m.n_prev > 1) d -= *(const f32x4*)(rel(rl, m.k_prev[1]) + off);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float r = d[i] / __builtin_fmaf(fabsf(yv[i]), m.rtol, m.atol);
+      sum = __builtin_fmaf(r, r, sum);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) m.err_partials[(b * 16 + rq * 4 + cq) * 4 + wave] = sum;
+  } else {
+    const float hs = m.h_ptr ? *(ConstF*)m.h_ptr : 1.0f;
+    float* const o1 = rel(rl, m.out1);
+    float* const o2 = rel(rl, m.out2);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+    if (yp) s1 = *(const f32x4*)(yp + off);
+    f32x4 s2 = s1;
+    for (int j = 0; j < m.n_prev; ++j) {
+      const f32x4 kv = *(const f32x4*)(rel(rl, m.k_prev[j]) + off);
+      s1 = fma4(kv, (m.c_dev ? ((ConstF*)m.c_dev)[j] : m.c1[j]) * hs, s1);
+      if (o2) s2 = fma4(kv, m.c2[j] * hs, s2);
+    }
+    if (o1) *(f32x4*)(o1 + off) = s1;
+    if (o2) *(f32x4*)(o2 + off) = s2;
   }
   wait_vmcnt<0>();
   if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1330,14 +1477,26 @@ __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArg
   }
   fence = __builtin_amdgcn_readfirstlane(fence);
   const ConvArgs* table = pa.table;
+  int n_layers = pa.n_layers;
+  {
+    typedef const __attribute__((address_space(4))) int ConstI;
+    const int* skip = table[0].skip;
+    if (skip && *(ConstI*)skip) return;   // an adaptive solver that finished while this launch was queued (uniform)
+    if (pa.n_layers_ptr) {   // a device-side controller picks the section of the table: {first row, rows}
+      const int row0 = ((ConstI*)pa.n_layers_ptr)[0], n_dev = ((ConstI*)pa.n_layers_ptr)[1];
+      if (row0 < 0 || n_dev <= 0 || row0 + n_dev > n_layers) return;
+      table += row0;
+      n_layers = n_dev;
+    }
+  }
   const float* src = table[0].src1;
   const float* u = table[0].w_wino;
-  for (int l = 0; l < pa.n_layers; ++l) {
+  for (int l = 0; l < n_layers; ++l) {
     typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
     const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
     const float* src_next = src;
     const float* u_next = u;
-    if (l + 1 < pa.n_layers) {
+    if (l + 1 < n_layers) {
       src_next = table[l + 1].src1;
       u_next = table[l + 1].w_wino;
       if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
@@ -1345,15 +1504,17 @@ __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArg
         asm volatile("" ::"v"(v));
       }
     }
-    const Hook16 hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6};
-    wino_layer16(uniform_ptr(src), uniform_ptr(u), a, b, cq, rq, smem, hk);
+    const Hook16 hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
+                       pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l)};
+    if (a.combine >= 4) ew_row16(a, b, cq, rq, hk);
+    else wino_layer16(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, b, cq, rq, smem, hk);
     src = src_next;
     u = u_next;
   }
 }
 
 int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                          float* out_nchw, hipStream_t stream) {
+                          float* out_nchw, hipStream_t stream, const int* n_layers_ptr, const unsigned long long* reloc) {
   static bool attr_set = false;
   ODEHIP_REQUIRE(batch >= 1 && batch <= 16, "wino_persist16: batch %d out of range", batch);
   if (!attr_set) {
@@ -1367,6 +1528,8 @@ int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, un
   memset(&pa, 0, sizeof(pa));
   pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
   pa.out_nchw = out_nchw;
+  pa.n_layers_ptr = n_layers_ptr;
+  pa.reloc = reloc;
   // Periods of 0.18 us the producers sleep in front of their first poll (a polling wave takes issue slots from the consumer wave of
   // its SIMD).  Sweep, forward trajectory B = 4, T = 10, rk4 (ms): 0: 1.07, 1: 0.90, 2: 0.66, 3: 0.605, 4: 0.596, 6: 0.619; B = 12 / 16:
   // 3: 0.88 / 0.80, 4: 0.621 / 0.620, 5: 0.608 / 0.617.

@@ -624,7 +624,15 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   const int C = f->channels[0];
   const size_t st_b = (size_t)batch * C * kPix * 4, st_f = st_b / 4;
   const long long n4 = (long long)st_f / 4;
-  const int n_conv_partials = batch * (C / 32) * 2 * 4;
+  // error-norm partials the attempts' last layers write: 4 per workgroup of the per-layer grid -- or, on the sixteen-workgroup walk
+  // (batch <= 16, 64-channel stack, walk available), 64 per sample
+  bool walk_ok = false;
+  if (all_64(f)) {
+    PersistScope probe;
+    if ((rc = probe.begin(f, nullptr, 1)) != ODEHIP_OK) return rc;
+    walk_ok = probe.recording();
+  }
+  const int n_conv_partials = walk_ok && persist_partials_per_sample(batch) == 64 ? batch * 64 : batch * (C / 32) * 2 * 4;
   const int red_grid = 256;
 
   // the context of this solve: on the stack for a synchronous call, in a free slot for an asynchronous one
@@ -666,11 +674,7 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   bool saving = false;
   char* bws = base + al256(odehip_dopri5_workspace_bytes(f, batch, n_times));
   const BwdLayout BL(f, batch, n_times, save_max_accept > 0 ? save_max_accept : 1);
-  if (save_max_accept > 0 && all_64(f) && !g_reduce_cb && n_times > 1) {
-    PersistScope probe;
-    if ((rc = probe.begin(f, nullptr, 1)) != ODEHIP_OK) return rc;
-    saving = probe.recording();
-  }
+  if (save_max_accept > 0 && all_64(f) && !g_reduce_cb && n_times > 1) saving = walk_ok;
 
   // exact-global mode: the kernels below read ONE already all-reduced scalar instead of the local partial arrays
   const bool global_norm = g_reduce_cb != nullptr;

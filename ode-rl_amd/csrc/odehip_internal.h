@@ -132,7 +132,11 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
 int launch_ew_row(const ConvArgs& a, hipStream_t stream);
 // forward tables of a 64-channel stack at batch <= 16: sixteen workgroups per sample (conv_wino.hip, wino_persist16_kernel)
 int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                          float* out_nchw, hipStream_t stream);   // an elementwise row (combine == 4) as an ordinary launch
+                          float* out_nchw, hipStream_t stream, const int* n_layers_ptr = nullptr, const unsigned long long* reloc = nullptr);
+// error-norm / norm-row partials per sample that a walk of `batch` samples writes: 64 on the sixteen-workgroup walk (batch <= 16, walk
+// available and not switched off), else the per-layer kernels' 16 (64-channel stacks).  Decided BEFORE the rows run: a controller must
+// know how many partials to add.
+int persist_partials_per_sample(int batch);   // an elementwise row (combine == 4) as an ordinary launch
 int launch_wino(const ConvArgs& a, hipStream_t stream);
 int launch_wino5(const ConvArgs& a, hipStream_t stream);  // 5x5 layers with a.w_wino (conv_wino5.hip); 1 = no such form, run the direct kernel
 int launch_bf16(const ConvArgs& a, hipStream_t stream);

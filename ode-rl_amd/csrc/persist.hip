@@ -187,6 +187,17 @@ __global__ void persist_guard_kernel(const GuardArgs a) {
       a.p[r][i] = __builtin_nanf("");
 }
 
+static bool walk16_on() {
+  static const bool on16 = [] { const char* e = getenv("ODEHIP_PERSIST16"); return !(e && e[0] == '0'); }();
+  return on16;
+}
+
+// (see odehip_internal.h) -- takes the lock: not to be called inside a PersistScope
+int persist_partials_per_sample(int batch) {
+  std::lock_guard<std::mutex> g(g_persist.mu);
+  return batch <= 16 && walk16_on() && persist_available() ? 64 : 16;
+}
+
 bool persist_switch_on() {
   std::lock_guard<std::mutex> g(g_persist.mu);
   if (g_persist.enabled == 0) return false;
@@ -352,19 +363,27 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     // batches up to 16: forward tables of a 64-channel stack take the sixteen-workgroups-per-sample walk (a layer's matrix work is
     // split four times finer; bit-identical results)
     bool small16 = false;
-    if (table && !wide && !adaptive && batch <= 16 && hbuf && !rows_dev_ && !reloc_dev_) {
-      static const bool on16 = [] { const char* e = getenv("ODEHIP_PERSIST16"); return !(e && e[0] == '0'); }();
-      small16 = on16;
+    if (table && !wide && batch <= 16 && walk16_on()) {
+      small16 = true;
       for (int i = 0; i < rec_.count && small16; ++i) {
         const ConvArgs& a = rec_.items[i];
+        if (a.combine >= 4) continue;   // elementwise / norm rows
         small16 = a.qin == 16 && a.qout == 16 &&
                   (a.combine == 0 || a.combine == 2 || a.combine == 3 ||
-                   (a.combine == 1 && a.h_by_value && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order));
+                   (a.combine == 1 && ((a.h_by_value && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order) ||
+                                       (a.cmb.order == 1 && !(a.cmb.err_partials && (a.cmb.out2 || a.cmb.out2_nchw))))));
+        // (a reverse-sweep row that falls to the shared epilogue must not carry relocatable pointers: the adaptive drivers keep to two
+        // constant-coefficient targets)
+      }
+      if (adaptive && !small16) {   // an adaptive table counts on 64 partials per sample here (persist_partials_per_sample)
+        set_error("persistent walk: an adaptive table of batch %d has a row the sixteen-workgroup walk does not take", batch);
+        return ODEHIP_EINVAL;
       }
     }
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
-      if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream);
+      if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream,
+                                              rows_dev_, reloc_dev_);
       else
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
                                kPersistGrid, stream, wide, adaptive, rows_dev_, reloc_dev_);
@@ -377,6 +396,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
         table_rows_ = rec_.count;
         table_wide_ = wide;
         table_adaptive_ = adaptive;
+        table_small16_ = small16;
         return rc;
       }
       g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
@@ -400,8 +420,11 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
 int PersistScope::relaunch(int batch, unsigned* sync, hipStream_t stream, bool sync_is_zero) {
   ODEHIP_REQUIRE(launched_ && table_ && !volatile_, "persistent relaunch without a table");
   if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
-  const int rc = launch_wino_persist(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
-                                     kPersistGrid, stream, table_wide_, table_adaptive_, rows_dev_, reloc_dev_);
+  const int rc = table_small16_
+                     ? launch_wino_persist16(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
+                                             stream, rows_dev_, reloc_dev_)
+                     : launch_wino_persist(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
+                                           kPersistGrid, stream, table_wide_, table_adaptive_, rows_dev_, reloc_dev_);
   if (rc == ODEHIP_OK) ++g_persist.launches;
   return rc;
 }
