@@ -536,14 +536,17 @@ def main():
             # the whole trajectory is ONE launch of wino_persist_kernel: its algorithmic work = every layer of every f evaluation
             # (339.7 MFLOP per latent frame for A, T=10); duration = the timed region / steps (the copy of
             # z0, the layout kernel and two tiny fills ride along: < 2 %)
-            kernel, launches, flop_per_launch = ("wino_persist_kernel" if a.shape == "A" else "wino_persist_v_kernel"), a.steps, F_f * nfe_per_step
+            # (batches up to 16 walk with sixteen workgroups per sample: wino_persist16_kernel)
+            small16 = a.shape == "A" and a.batch <= 16 and os.environ.get("ODEHIP_PERSIST16") != "0"
+            kernel, launches, flop_per_launch = ("wino_persist16_kernel" if small16 else ("wino_persist_kernel" if a.shape == "A" else "wino_persist_v_kernel")), a.steps, F_f * nfe_per_step
         elif fused_bf16 and persistent == a.steps and a.method != "dopri5":
             # bf16, 64-channel stack: the whole trajectory is ONE launch of ftraj_bf16_kernel (one workgroup per sample)
             kernel, launches, flop_per_launch = "ftraj_bf16_kernel", a.steps, F_f * nfe_per_step
         elif a.method == "dopri5" and persistent > 0 and a.dtype == "f32":
             # dopri5 forward: every attempted step (6 evaluations of f) is one launch of wino_persist_kernel; the two evaluations
             # of the initial-step search run as per-layer launches and are left out of this entry
-            kernel, launches, flop_per_launch = ("wino_persist_kernel" if a.shape == "A" else "wino_persist_v_kernel") + " (one launch per attempted step)", persistent, 6 * F_f
+            small16 = a.shape == "A" and a.batch <= 16 and os.environ.get("ODEHIP_PERSIST16") != "0"
+            kernel, launches, flop_per_launch = ("wino_persist16_kernel" if small16 else ("wino_persist_d_kernel" if a.shape == "A" else "wino_persist_v_kernel")) + " (one launch per attempted step)", persistent, 6 * F_f
             note = "dev time of the whole region / persistent launches; the 2 evaluations of the initial-step search ride along"
         elif fused_bf16:
             kernel, launches, flop_per_launch = "fstack_bf16_kernel", nfe_per_step * a.steps, F_f      # one launch per evaluation of f
