@@ -517,6 +517,8 @@ class PendingDopri5:
     def collect(self):
         """(stats dict, saved) -- saved = (workspace, slots) if the activations of the accepted steps were kept, else None."""
         global _dopri5_save_slots, _async_attempts
+        if isinstance(self._result, BaseException):   # the solve failed: every later look at it raises the same error
+            raise self._result
         if self._result is None:
             if self in _pending_solves:
                 _pending_solves.remove(self)
@@ -526,6 +528,9 @@ class PendingDopri5:
             lib = _lib.load()
             try:
                 _lib.check(lib.odehip_odeint_dopri5_collect(int(self.token), stats, log, LOG_CAP, ctypes.byref(saved)))
+            except BaseException as e:
+                self._result = e
+                raise
             finally:
                 self._keep = None
             k = min(int(stats[1]), LOG_CAP)
