@@ -188,7 +188,7 @@ def visible_gpu_count():
     return n
 
 
-def model_context(a, dev, T):
+def model_context(a, dev, T, method=None):
     """End-to-end ODEConvGRU (models/ODEConvGRU.py:57-88 around the hot path) at this run's batch / frames / method: predicted frames/s
     of `forward` under no_grad and of a training step (MSE loss, loss.backward(), fused Adam), Moving-MNIST-shaped frames rendered
     on the device, random-init weights of the reference's architecture (64-channel latents, 3 ODE layers).  Context, not the metric."""
@@ -198,8 +198,9 @@ def model_context(a, dev, T):
     from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
     from ode_rl_amd.optim import FusedAdam
     torch.manual_seed(0)
+    method = method or a.method
     opt = ap.Namespace(resolution=64, n_downs=2, conv_encoder_out_ch=64, in_channels=1, n_ode_layers=3, neural_ode_n_units=64,
-                       neural_ode_decoder_out_ch=64, decode_diff_method=a.method, mem=False, z_sample=False)
+                       neural_ode_decoder_out_ch=64, decode_diff_method=method, mem=False, z_sample=False)
     m = ODEConvGRU(opt, torch.device("cpu")).to(dev)
     batch = next(MovingMNISTSynthetic(T, T, num_objects=[2], batch_size=a.batch, device=dev, seed=0))
     frames, truth = batch["observed_data"] + 0.5, batch["data_to_predict"] + 0.5      # train_test.py:180
@@ -235,7 +236,7 @@ def model_context(a, dev, T):
     finally:
         ode_rl_amd.set_async_dopri5(was_async)
     return {"what": "ODEConvGRU end to end (conv encoder + ODEConvGRUCell + DiffEqSolver + conv decoder), context only", "batch": a.batch,
-            "frames_in": T, "frames_out": T, "method": a.method, "dtype": a.dtype, "steps": n,
+            "frames_in": T, "frames_out": T, "method": method, "dtype": a.dtype, "steps": n,
             "forward": {"ms": tf * 1e3, "value": a.batch * T / tf, "unit": "predicted frames/s"},
             "train_step": {"ms": tt * 1e3, "value": a.batch * T / tt, "unit": "predicted frames/s",
                            "what": "MSE loss + loss.backward() + fused Adam step (ode_rl_amd.optim.FusedAdam)"}}
@@ -507,6 +508,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_model and not a.train and a.shape == "A" and not a.graph:
         try:
             model_ctx = model_context(a, dev, T)
+            if a.method != "dopri5":   # ... and with the reference's DEFAULT decoder solver (configs.yaml:79 decode_diff_method 'dopri5')
+                model_ctx["with_reference_default_solver_dopri5"] = {k: v for k, v in model_context(a, dev, T, "dopri5").items()
+                                                                     if k in ("method", "forward", "train_step")}
         except Exception as e:   # context only (library convolutions either side of the path): never fails the record
             model_ctx = {"error": repr(e)[:300]}
 
