@@ -340,6 +340,11 @@ int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esp
                       int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
                       hipStream_t stream) {
   int rc;
+  if (ks == 5) {   // fp32 5x5: the Winograd-domain kernel (36 instead of 100 multiplies per 2x2 outputs, wgrad_wino5.hip) unless switched off
+    rc = launch_wgrad_wino5(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads, a_quad0, write_bias,
+                            stream);
+    if (rc != 1) return rc;
+  }
   if (ks == 1) return launch_tile_part<1, 0, 1>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0,
                                                 a_quads, a_quad0, write_bias, stream);
   if (ks == 3) return launch_tile_part<3, 0, 3>(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0,

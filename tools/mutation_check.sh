@@ -13,7 +13,7 @@ SED[midpoint_half]='s/c.c1\[0\] = 0.5f;/c.c1[0] = 0.45f;/'
 SED[codec_convt_tap]='s/if (parity == 0) { k = t == 0 ? 1 : 3;/if (parity == 0) { k = t == 0 ? 3 : 1;/'        # frame decoder: kernel rows of the even output rows swapped
 SED[codec_enc_slope]='s/v = w2\[((size_t)co \* kEncMid + 4 \* kq + j) \* 9 + tap\];/v = w2[((size_t)co * kEncMid + 4 * kq + j) * 9 + (8 - tap)];/'  # frame encoder: second conv's filter flipped
 SED[wino5_bt_coef]='s/out\[0\] = fma2(4.0f, in\[0\], fma2(-5.0f, in\[2\], in\[4\]));/out[0] = fma2(4.0f, in[0], fma2(-4.0f, in[2], in[4]));/'      # F(2x2,5x5): B^T row 0: -5 -> -4
-SED[wino5_at_coef]='s/(i == 3 ? 2.0f : (i == 4 ? -2.0f : 1.0f))/(i == 3 ? 2.0f : (i == 4 ? -1.0f : 1.0f))/'    # F(2x2,5x5): A^T row 1: -2 -> -1
+SED[wino5_at_coef]='s/^  return i == 0 ? 0.0f : (i == 1 ? 1.0f : (i == 2 ? -1.0f : (i == 3 ? 2.0f : (i == 4 ? -2.0f : 1.0f))));/  return i == 0 ? 0.0f : (i == 1 ? 1.0f : (i == 2 ? -1.0f : (i == 3 ? 2.0f : (i == 4 ? -1.0f : 1.0f))));/'    # F(2x2,5x5): A^T row 1: -2 -> -1
 SED[wgrad_wino_g]='s/const float hs = 0.5f \* (u\[1\]\[j\] + u\[2\]\[j\]), hd = 0.5f \* (u\[1\]\[j\] - u\[2\]\[j\]);/const float hs = 0.5f * (u[1][j] + u[2][j]), hd = 0.4f * (u[1][j] - u[2][j]);/'   # Winograd-domain weight gradient: one G entry 0.5 -> 0.4
 SED[wgrad_wino_at]='s/\*(f32x4\*)(wr + (4 \* i + 2) \* kWwPlane) = t\[i\]\[0\] - t\[i\]\[1\];/*(f32x4*)(wr + (4 * i + 2) * kWwPlane) = t[i][0] + t[i][1];/'   # ... and one sign of A dY A^T
 # ---- round 3: the adaptive walk, the device-driven adjoint, the saving forward, the 16-workgroup walk
@@ -22,8 +22,9 @@ SED[adapt_ew_coef]='s/    const float c1 = (m.c_dev ? ((ConstF\*)m.c_dev)\[j\] :
 SED[adjoint_dense_weight]='s/  const double C2 = d7 - 4.0 \* d1 - 5.0 \* b + 16.0 \* m;\n  return x \* d1/XX/;s/^__device__ double adj_dense_weight(const AdjCtl\* st, int s, double x) {  \/\/ dp5::dense_weight/__device__ double adj_dense_weight(const AdjCtl* st, int s, double x) { x *= 0.97;/'   # device controller: dense-output weights evaluated at the wrong point
 SED[walk16_out_transform]='s/      val = pk_sub(pk_sub(\*(const f32x4\*)(x + 1024) + bias4, \*(const f32x4\*)(x + 2048)), \*(const f32x4\*)(x + 3072));/      val = pk_sub(pk_sub(*(const f32x4*)(x + 1024) + bias4, *(const f32x4*)(x + 3072)), *(const f32x4*)(x + 2048)) * 1.001f;/'   # 16-workgroup walk: second half of the output transform
 SED[saving_slot_offset]='s/  fa.off_y1 = (long long)(6 \* BL.st);/  fa.off_y1 = (long long)(5 * BL.st);/'                # saving forward: y1 read from the wrong stage input of the slot
+SED[wgrad_wino5_bt]='s/  out\[0\] = w5_fma2(4.0f, in\[0\], w5_fma2(-5.0f, in\[2\], in\[4\]));/  out[0] = w5_fma2(4.0f, in[0], w5_fma2(-4.0f, in[2], in[4]));/'   # Winograd F(2x2,5x5) weight gradient: B^T row 0
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4"
+TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
@@ -42,7 +43,7 @@ build)
     echo "built $m"
   done ;;
 run)
-  # MUT_ONLY="name name ...": only those mutants, appended to the summary (a GPU lease is too short for all fifteen in one go)
+  # MUT_ONLY="name name ...": only those mutants, appended to the summary (a GPU lease is too short for all sixteen in one go)
   out=$ROOT/gpurun_out/mutation_check.txt
   cd "$ROOT"
   bad=0
