@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 8 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 9 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -422,6 +422,27 @@ int odehip_pack_frame_decoder(const float* w1, const float* b1, const float* w2,
                               void* stream);
 int odehip_frame_decode(const float* pack, const float* latents, int n_images, int in_ch, int out_ch, float negative_slope,
                         int apply_sigmoid, float* out, void* stream);
+/* Backward of the two fused launches above (frame_codec_backward.hip) -- what `loss.backward()` needs from the Encoder / Decoder of
+ * models/ODEConvGRU.py:101-140 in a training step, for ONE frame channel and 32 / 64 latent channels (other shapes: rc != 0, the
+ * caller keeps the library's backward).  The 32x32 intermediates are recomputed in LDS from the forward's inputs; weight gradients
+ * are summed in a fixed order (bitwise reproducible).  All gradients are WRITTEN (not accumulated), in the parameters' own layouts.
+ * `workspace`: device scratch of odehip_frame_*_backward_workspace_floats floats (0 = unsupported shape).
+ *
+ * Decoder: pack = the forward's pack, w1 = the first ConvTranspose2d's weight (in_ch, 32, 4, 4) as it lies; latents (N, in_ch, 16,
+ * 16) and pred (N, 1, 64, 64) = the forward's input and output, g_out = dL/d pred (sigmoid_applied: pred is after the sigmoid and
+ * its derivative pred (1 - pred) is applied here).  Out: g_latents (N, in_ch, 16, 16), dw1 (in_ch, 32, 4, 4), db1 (32), dw2 (32, 1,
+ * 4, 4), db2 (1). */
+size_t odehip_frame_decode_backward_workspace_floats(int n_images, int in_ch, int out_ch);
+int odehip_frame_decode_backward(const float* pack, const float* w1, const float* latents, const float* pred, const float* g_out,
+                                 int n_images, int in_ch, int out_ch, float negative_slope, int sigmoid_applied, float* g_latents,
+                                 float* dw1, float* db1, float* dw2, float* db2, float* workspace, size_t workspace_floats, void* stream);
+/* Encoder: pack = the forward's pack, w2 = the second Conv2d's weight (out_ch, 16, 3, 3); frames (B, T, 1, 64, 64),
+ * out_time_first = the forward's result (T, B, out_ch, 16, 16), g_out_time_first = dL/d of it in the same layout.  The frames
+ * receive no gradient.  Out: dw1 (16, 1, 3, 3), db1 (16), dw2 (out_ch, 16, 3, 3), db2 (out_ch). */
+size_t odehip_frame_encode_backward_workspace_floats(int batch, int n_frames, int in_ch, int out_ch);
+int odehip_frame_encode_backward(const float* pack, const float* w2, const float* frames, const float* out_time_first,
+                                 const float* g_out_time_first, int batch, int n_frames, int in_ch, int out_ch, float negative_slope,
+                                 float* dw1, float* db1, float* dw2, float* db2, float* workspace, size_t workspace_floats, void* stream);
 
 /* odehip_odeint_fixed runs a forward-only trajectory of a 64-channel fp32 stack as ONE persistent launch (the four workgroups of a
  * sample hand layers to each other through L2 instead of through launch boundaries).  On by default

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
-ABI_VERSION = 8   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
+ABI_VERSION = 9   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
 MAX_LAYERS = 8
 MAX_STAGES = 7
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
@@ -115,6 +115,12 @@ SIGNATURES = {
     "odehip_pack_frame_decoder": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2),
     "odehip_frame_encode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+    "odehip_frame_decode_backward_workspace_floats": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "odehip_frame_decode_backward": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] +
+                                     [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "odehip_frame_encode_backward_workspace_floats": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "odehip_frame_encode_backward": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float] +
+                                     [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_frame_decode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "odehip_mmnist_render": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,

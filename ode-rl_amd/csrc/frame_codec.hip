@@ -15,33 +15,12 @@
 // 16-pixel block, kq = lane / 16) reads ONE 16-byte quad `kq` of its (shifted) input pixel: component j of it is its B value for
 // the j-th of four v_mfma_f32_16x16x4_f32, whose k index therefore runs over channels {j, 4 + j, 8 + j, 12 + j} of a 16-channel
 // group -- any fixed permutation of k is fine as long as the weights are packed the same way, which the pack kernels below do.
-#include <stddef.h>
-
-#include "conv_common.h"
+#include "frame_codec.h"
 
 namespace odehip {
 
-constexpr int kFrame = 64;     // frames are 64x64: two stride-2 layers take them to the path's 16x16 latents
-constexpr int kHalf = 32;      // the intermediate resolution
-constexpr int kEncMid = 16;    // Encoder: chan = 16 (ODEConvGRU.py:105)
-constexpr int kDecMid = 32;    // Decoder: chan = 32 (:131)
-constexpr int kCodecThreads = 256;
-
-// ConvTranspose2d(k = 4, stride 2, pad 1): output row 2 i + a receives input row i + d through kernel row k, for two (k, d) per
-// parity a (o = 2 iy - 1 + k):  a = 0: (1, 0), (3, -1);   a = 1: (0, +1), (2, 0).  Same for columns.
-__host__ __device__ __forceinline__ void convt_tap(int parity, int t, int& k, int& d) {
-  if (parity == 0) { k = t == 0 ? 1 : 3; d = t == 0 ? 0 : -1; }
-  else             { k = t == 0 ? 0 : 2; d = t == 0 ? 1 : 0; }
-}
-
-__device__ __forceinline__ float leaky(float v, float slope) { return v > 0.0f ? v : v * slope; }
-
 // ------------------------------------------------------------------------------------------------------------------ packing
 // Encoder pack (floats): [w1 (16, in_ch, 3, 3) as is | b1 (16) | pad to x4 | A2 [tap 9][kq 4][co][j 4] = w2[co][4 kq + j][tap] | b2]
-__host__ __device__ inline size_t enc_off_b1(int in_ch) { return (size_t)kEncMid * in_ch * 9; }
-__host__ __device__ inline size_t enc_off_a2(int in_ch) { return (enc_off_b1(in_ch) + kEncMid + 3) & ~(size_t)3; }
-__host__ __device__ inline size_t enc_off_b2(int in_ch, int out_ch) { return enc_off_a2(in_ch) + (size_t)9 * 16 * out_ch; }
-__host__ __device__ inline size_t enc_pack_floats(int in_ch, int out_ch) { return enc_off_b2(in_ch, out_ch) + out_ch; }
 
 __global__ void pack_frame_encoder_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                           const float* __restrict__ b2, int in_ch, int out_ch, float* __restrict__ dst) {
@@ -62,10 +41,6 @@ __global__ void pack_frame_encoder_kernel(const float* __restrict__ w1, const fl
 
 // Decoder pack (floats): [A1 [parity 4][tap 4][g][kq 4][co 32][j 4] = w1[16 g + 4 kq + j][co][ky][kx] | b1 (32) |
 //                         W2 [parity 4][tap 4][o][ci 32] = w2[ci][o][ky][kx] | b2 (out_ch)]      (ky, kx) = convt_tap(parity, tap)
-__host__ __device__ inline size_t dec_off_b1(int in_ch) { return (size_t)in_ch * 512; }
-__host__ __device__ inline size_t dec_off_w2(int in_ch) { return dec_off_b1(in_ch) + kDecMid; }
-__host__ __device__ inline size_t dec_off_b2(int in_ch, int out_ch) { return dec_off_w2(in_ch) + (size_t)16 * out_ch * kDecMid; }
-__host__ __device__ inline size_t dec_pack_floats(int in_ch, int out_ch) { return (dec_off_b2(in_ch, out_ch) + out_ch + 3) & ~(size_t)3; }
 
 __global__ void pack_frame_decoder_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                           const float* __restrict__ b2, int in_ch, int out_ch, float* __restrict__ dst) {
@@ -108,9 +83,6 @@ struct EncArgs {
   float slope;
 };
 
-constexpr int kImgW = kFrame + 1;   // row / column 0 = the zero border at index -1 (stride 2, pad 1 never reaches index 64)
-constexpr int kMidW = kHalf + 1;
-
 // One workgroup per frame.  LDS: img [in_ch][65][65] floats | mid [quad 4][33][33] x 16 B | A2 [tap 9][kq 4][co] x 16 B.
 template <int COB>  // out_ch / 16
 __global__ __launch_bounds__(kCodecThreads) void frame_encode_kernel(const EncArgs a) {
@@ -121,51 +93,17 @@ __global__ __launch_bounds__(kCodecThreads) void frame_encode_kernel(const EncAr
   f32x4* const a2 = mid + 4 * kMidW * kMidW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.x, b = n / a.n_frames, t = n - b * a.n_frames;
-  typedef const __attribute__((address_space(4))) float ConstF;  // uniform reads of the small weights: scalar loads
-  ConstF* const pk = (ConstF*)a.pack;
 
   // ---- phase 0: frame -> LDS (with its zero border), conv2's weights -> LDS
-  for (int i = tid; i < a.in_ch * (2 * kImgW - 1); i += kCodecThreads) {
-    const int ic = i / (2 * kImgW - 1), e = i - ic * (2 * kImgW - 1);
-    img[(size_t)ic * kImgW * kImgW + (e < kImgW ? e : (e - kImgW + 1) * kImgW)] = 0.0f;
-  }
-  for (int i = tid; i < 4 * (2 * kMidW - 1); i += kCodecThreads) {
-    const int q = i / (2 * kMidW - 1), e = i - q * (2 * kMidW - 1);
-    mid[q * kMidW * kMidW + (e < kMidW ? e : (e - kMidW + 1) * kMidW)] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const float* const src = a.frames + (size_t)n * a.in_ch * kFrame * kFrame;
-  for (int i = tid; i < a.in_ch * kFrame * kFrame / 4; i += kCodecThreads) {
-    const int ic = i / (kFrame * kFrame / 4), e = i - ic * (kFrame * kFrame / 4), r = e / (kFrame / 4), c4 = e - r * (kFrame / 4);
-    const f32x4 v = *(const f32x4*)(src + (size_t)i * 4);
-    float* d = img + (size_t)ic * kImgW * kImgW + (r + 1) * kImgW + 4 * c4 + 1;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
+  enc_stage_frame(a.frames + (size_t)n * a.in_ch * kFrame * kFrame, a.in_ch, img, mid, tid);
   {
     const f32x4* const g = (const f32x4*)(a.pack + enc_off_a2(a.in_ch));
     for (int i = tid; i < 9 * 4 * out_ch; i += kCodecThreads) a2[i] = g[i];
   }
   __syncthreads();
 
-  // ---- phase 1: Conv2d(in_ch, 16, 3, 2, 1) + LeakyReLU on the VALU: 4 output pixels per thread, all 16 channels
-  for (int s = 0; s < kHalf * kHalf / kCodecThreads; ++s) {
-    const int p = tid + s * kCodecThreads, oy = p / kHalf, ox = p - oy * kHalf;
-    float acc[kEncMid];
-#pragma unroll
-    for (int c = 0; c < kEncMid; ++c) acc[c] = pk[enc_off_b1(a.in_ch) + c];
-    for (int ic = 0; ic < a.in_ch; ++ic) {
-      const float* ip = img + (size_t)ic * kImgW * kImgW + 2 * oy * kImgW + 2 * ox;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float v = ip[(k / 3) * kImgW + (k % 3)];
-#pragma unroll
-        for (int c = 0; c < kEncMid; ++c) acc[c] = __builtin_fmaf(pk[(c * a.in_ch + ic) * 9 + k], v, acc[c]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      mid[(q * kMidW + oy + 1) * kMidW + ox + 1] =
-          f32x4{leaky(acc[4 * q], a.slope), leaky(acc[4 * q + 1], a.slope), leaky(acc[4 * q + 2], a.slope), leaky(acc[4 * q + 3], a.slope)};
-  }
+  // ---- phase 1: Conv2d(in_ch, 16, 3, 2, 1) + LeakyReLU on the VALU (frame_codec.h)
+  enc_conv1_to_lds(a.pack, a.in_ch, a.slope, img, mid, tid);
   __syncthreads();
 
   // ---- phase 2: Conv2d(16, out_ch, 3, 2, 1) on the MFMA: wave w owns output rows 4w..4w+3 (one 16-pixel block each) x all co
@@ -218,10 +156,6 @@ struct DecArgs {
   int sigmoid;
 };
 
-constexpr int kZRows = 6, kZW = 18;          // latent rows 4q-1 .. 4q+4, columns -1 .. 16
-constexpr int kMRows = 10, kMW = 34;         // intermediate rows 8q-1 .. 8q+8, columns -1 .. 32
-constexpr int kMPix = 36;                    // floats per intermediate pixel (32 channels + 4: a 2-pixel lane stride is 72 words)
-
 // One workgroup per (image, quarter q of the output rows): output rows 16q .. 16q+15 need intermediate rows 8q-1 .. 8q+8, which
 // need latent rows 4q-1 .. 4q+4.  LDS: z [quad in_ch/4][6][18] x 16 B | mid [10][34][36] floats: 76 KiB at in_ch = 64, two
 // workgroups per CU.  ConvTranspose(k4, s2, p1) = four 2x2 convolutions, one per output parity: wave w takes parity (w >> 1, w & 1)
@@ -237,89 +171,8 @@ __global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_kernel(const De
   const int n = blockIdx.x >> 2, q = blockIdx.x & 3;
   const int pa = wave >> 1, pb = wave & 1;
 
-  // ---- phase 0: latent rows -> LDS as channel quads, zero outside the image; the intermediate's border columns
-  for (int i = tid; i < 4 * G * kZRows * kZW; i += kCodecThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < kMRows * 2; i += kCodecThreads) {
-    float* m = mid + ((i >> 1) * kMW + (i & 1) * (kMW - 1)) * kMPix;
-#pragma unroll
-    for (int c = 0; c < kDecMid; c += 4) *(f32x4*)(m + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  const float* const src = a.latents + (size_t)n * in_ch * 256;
-  for (int i = tid; i < in_ch * kZRows * 4; i += kCodecThreads) {
-    const int ci = i / (kZRows * 4), e = i - ci * (kZRows * 4), rr = e >> 2, c4 = e & 3;
-    const int zr = 4 * q - 1 + rr;
-    if (zr < 0 || zr > 15) continue;
-    const f32x4 v = *(const f32x4*)(src + (size_t)ci * 256 + zr * 16 + 4 * c4);
-    float* d = (float*)(z + ((ci >> 2) * kZRows + rr) * kZW + 4 * c4 + 1) + (ci & 3);
-    d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
-  }
-  __syncthreads();
-
-  // ---- phase 1: ConvTranspose2d(in_ch, 32, 4, 2, 1) + LeakyReLU on the MFMA.  This wave: the five intermediate rows of parity pa
-  // (local rows mr = 2 r + 1 - pa; row 8q-1 is odd), columns of parity pb (16 per row = one block), both 16-channel halves.
-  {
-    const int nn = lane & 15, kq = lane >> 4;
-    f32x4 acc[2][5];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-      for (int r = 0; r < 5; ++r) acc[cb][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4* const a1 = (const f32x4*)a.pack + (size_t)(pa * 2 + pb) * 4 * G * 4 * kDecMid + kq * kDecMid + nn;
-    // the weight fragments come straight from L2: those of the next tap are requested before this tap's MFMAs
-    f32x4 af[G][2], afn[G][2];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) af[g][cb] = a1[g * 4 * kDecMid + cb * 16];
-#pragma unroll 1
-    for (int tap = 0; tap < 4; ++tap) {
-      int ky, kx, dy, dx;
-      convt_tap(pa, tap >> 1, ky, dy);
-      convt_tap(pb, tap & 1, kx, dx);
-      (void)ky; (void)kx;
-      if (tap + 1 < 4) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) afn[g][cb] = a1[((tap + 1) * G + g) * 4 * kDecMid + cb * 16];
-      }
-      // intermediate row my = 8q - 1 + mr = 2 i' + pa (mr = 2 r + 1 - pa)  ->  latent row i' + dy, local index r - pa + 1 + dy
-      const f32x4* const zb = z + (kq * kZRows + 1 - pa + dy) * kZW + nn + dx + 1;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        f32x4 bf[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) bf[r] = zb[(4 * g * kZRows + r) * kZW];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int r = 0; r < 5; ++r) {
-            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].x, bf[r].x, acc[cb][r], 0, 0, 0);
-            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].y, bf[r].y, acc[cb][r], 0, 0, 0);
-            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].z, bf[r].z, acc[cb][r], 0, 0, 0);
-            acc[cb][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g][cb].w, bf[r].w, acc[cb][r], 0, 0, 0);
-          }
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) af[g][cb] = afn[g][cb];
-    }
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int c0 = cb * 16 + 4 * kq;
-      const f32x4 bias = *(const f32x4*)(a.pack + dec_off_b1(in_ch) + c0);
-#pragma unroll
-      for (int r = 0; r < 5; ++r) {
-        const int mr = 2 * r + 1 - pa, my = 8 * q - 1 + mr;
-        f32x4 v = acc[cb][r] + bias;
-        v = f32x4{leaky(v.x, a.slope), leaky(v.y, a.slope), leaky(v.z, a.slope), leaky(v.w, a.slope)};
-        if (my < 0 || my >= kHalf) v = f32x4{0.f, 0.f, 0.f, 0.f};  // rows beyond the intermediate image contribute nothing
-        *(f32x4*)(mid + (mr * kMW + 2 * nn + pb + 1) * kMPix + c0) = v;
-      }
-    }
-  }
+  // ---- phases 0, 1: latent rows -> LDS, ConvTranspose2d(in_ch, 32, 4, 2, 1) + LeakyReLU on the MFMA -> mid (frame_codec.h)
+  dec_mid_to_lds<G>(a.pack, a.latents + (size_t)n * in_ch * 256, q, a.slope, z, mid, tid, lane, wave);
   __syncthreads();
 
   // ---- phase 2: ConvTranspose2d(32, out_ch, 4, 2, 1) [+ sigmoid] on the VALU.  This wave: output pixels (16q + 2 il + pa,

@@ -1159,3 +1159,104 @@ def frame_decode(seq, latents, apply_sigmoid):
     _lib.check(lib.odehip_frame_decode(_ptr(pack), _ptr(latents), n, c1.in_channels, c2.out_channels, slope, 1 if apply_sigmoid else 0,
                                        _ptr(out), _stream()))
     return out
+
+
+
+def codec_backward_enabled():
+    """ODEHIP_CODEC_BACKWARD=0: the frame encoder / decoder run as library calls under autograd (the behaviour before round 3)."""
+    return os.environ.get("ODEHIP_CODEC_BACKWARD", "1") != "0"
+
+
+def frame_encoder_backward_supported(seq):
+    """The shapes csrc/frame_codec_backward.hip implements: one frame channel, 32 / 64 latent channels."""
+    if not frame_encoder_supported(seq):
+        return False
+    c1, c2, _ = _codec_layers(seq, torch.nn.Conv2d, 3, 16)
+    return c1.in_channels == 1 and c2.out_channels in (32, 64)
+
+
+def frame_decoder_backward_supported(seq):
+    if not frame_decoder_supported(seq):
+        return False
+    c1, c2, _ = _codec_layers(seq, torch.nn.ConvTranspose2d, 4, 32)
+    return c2.out_channels == 1 and c1.in_channels in (32, 64)
+
+
+class _FrameEncodeFn(torch.autograd.Function):
+    """frame_encode under autograd: forward = the fused launch, backward = odehip_frame_encode_backward (gradients of the four
+    parameter tensors; the frames carry none -- the caller checks that they do not ask for one)."""
+
+    @staticmethod
+    def forward(ctx, seq, frames, w1, b1, w2, b2):
+        out = frame_encode(seq, frames)
+        ctx.seq = seq
+        ctx.save_for_backward(frames, out, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        frames, out, w2 = ctx.saved_tensors
+        seq = ctx.seq
+        c1, c2, slope = _codec_layers(seq, torch.nn.Conv2d, 3, 16)
+        lib = _lib.load()
+        b, t = frames.shape[:2]
+        pack = _codec_pack(seq, c1, c2, lib.odehip_frame_encoder_pack_floats(1, c2.out_channels), lib.odehip_pack_frame_encoder, 1, c2.out_channels)
+        g = g.contiguous()
+        frames = frames.detach().contiguous()
+        dev = frames.device
+        dw1, db1 = torch.empty_like(c1.weight), torch.empty_like(c1.bias)
+        dw2, db2 = torch.empty_like(c2.weight), torch.empty_like(c2.bias)
+        nws = int(lib.odehip_frame_encode_backward_workspace_floats(b, t, 1, c2.out_channels))
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        _lib.check(lib.odehip_frame_encode_backward(_ptr(pack), _ptr(w2.detach().contiguous()), _ptr(frames), _ptr(out), _ptr(g), b, t, 1,
+                                                    c2.out_channels, slope, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2), _ptr(ws), nws, _stream()))
+        return None, None, dw1, db1, dw2, db2
+
+
+class _FrameDecodeFn(torch.autograd.Function):
+    """frame_decode (+ sigmoid) under autograd: backward = odehip_frame_decode_backward (latents' and the four parameters' gradients)."""
+
+    @staticmethod
+    def forward(ctx, seq, latents, apply_sigmoid, w1, b1, w2, b2):
+        pred = frame_decode(seq, latents, apply_sigmoid)
+        ctx.seq, ctx.apply_sigmoid = seq, bool(apply_sigmoid)
+        ctx.save_for_backward(latents, pred, w1)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        latents, pred, w1 = ctx.saved_tensors
+        seq = ctx.seq
+        c1, c2, slope = _codec_layers(seq, torch.nn.ConvTranspose2d, 4, 32)
+        lib = _lib.load()
+        lat = latents.detach().contiguous()
+        n = lat.numel() // (c1.in_channels * 256)
+        pack = _codec_pack(seq, c1, c2, lib.odehip_frame_decoder_pack_floats(c1.in_channels, 1), lib.odehip_pack_frame_decoder, c1.in_channels, 1)
+        g = g.contiguous()
+        g_lat = torch.empty_like(lat)
+        dw1, db1 = torch.empty_like(c1.weight), torch.empty_like(c1.bias)
+        dw2, db2 = torch.empty_like(c2.weight), torch.empty_like(c2.bias)
+        nws = int(lib.odehip_frame_decode_backward_workspace_floats(n, c1.in_channels, 1))
+        ws = torch.empty(nws, dtype=torch.float32, device=lat.device)
+        _lib.check(lib.odehip_frame_decode_backward(_ptr(pack), _ptr(w1.detach().contiguous()), _ptr(lat), _ptr(pred), _ptr(g), n, c1.in_channels, 1,
+                                                    slope, 1 if ctx.apply_sigmoid else 0, _ptr(g_lat), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                                    _ptr(ws), nws, _stream()))
+        return None, g_lat.view_as(latents), None, dw1, db1, dw2, db2
+
+
+def frame_encode_autograd(seq, frames):
+    """frame_encode as a differentiable op of the encoder's parameters (frames must not require a gradient)."""
+    if not frame_encoder_backward_supported(seq):
+        raise ValueError("frame_encode_autograd: one frame channel and 32 / 64 latent channels only")
+    if frames.requires_grad:
+        raise ValueError("frame_encode_autograd: no gradient with respect to the frames (use the library path)")
+    c1, c2, _ = _codec_layers(seq, torch.nn.Conv2d, 3, 16)
+    return _FrameEncodeFn.apply(seq, frames, c1.weight, c1.bias, c2.weight, c2.bias)
+
+
+def frame_decode_autograd(seq, latents, apply_sigmoid):
+    """frame_decode as a differentiable op of the latents and the decoder's parameters."""
+    if not frame_decoder_backward_supported(seq):
+        raise ValueError("frame_decode_autograd: one frame channel and 32 / 64 latent channels only")
+    c1, c2, _ = _codec_layers(seq, torch.nn.ConvTranspose2d, 4, 32)
+    return _FrameDecodeFn.apply(seq, latents, apply_sigmoid, c1.weight, c1.bias, c2.weight, c2.bias)

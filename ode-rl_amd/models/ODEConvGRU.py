@@ -2,9 +2,10 @@
 (conv encoder -> ODEConvGRUCell -> DiffEqSolver -> conv decoder -> sigmoid) around the HIP hot path.
 
 The strided encoder / transposed-conv decoder either side of the path are ONE fused HIP launch each
-when no gradient is wanted (csrc/frame_codec.hip: the 32x32 intermediate stays in LDS, the encoder writes time-first, the
-decoder reads the solver's (T,B,C,16,16) as it lies and applies the sigmoid); under autograd, and for structures other than
-the reference's n_downs = 2, they are library calls (MIOpen through torch).  Same module names so the reference's state_dict
+(csrc/frame_codec.hip: the 32x32 intermediate stays in LDS, the encoder writes time-first, the decoder reads the solver's
+(T,B,C,16,16) as it lies and applies the sigmoid), with their own backward under autograd (csrc/frame_codec_backward.hip: one
+frame channel, 32 / 64 latent channels); for other shapes under autograd, and for structures other than the reference's
+n_downs = 2, they are library calls (MIOpen through torch).  Same module names so the reference's state_dict
 loads, including the aliased keys (`diffeq_solver.ode_func.*` == `ode_decoder_func.*`, `ode_convgru_cell.ode_func.*` ==
 `ode_encoder_func.*`)."""
 import torch
@@ -38,14 +39,22 @@ class Encoder(nn.Module):
         return self.encoder(x)
 
     def _fused(self, x):
-        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return x.is_cuda and not wants_grad and tuple(x.shape[-2:]) == (64, 64) and hip_ops.frame_encoder_supported(self.encoder)
+        """0: library calls; 1: the fused launch (no gradient wanted); 2: the fused launch under autograd (csrc/frame_codec_backward.hip)."""
+        if not (x.is_cuda and tuple(x.shape[-2:]) == (64, 64) and hip_ops.frame_encoder_supported(self.encoder)):
+            return 0
+        if not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return 1
+        ok = hip_ops.codec_backward_enabled() and not x.requires_grad and hip_ops.frame_encoder_backward_supported(self.encoder)
+        return 2 if ok else 0
 
     def encode_time_first(self, frames):
         """frames (B,T,c,H,W) -> (T,B,C',H/4,W/4): `forward` on the flattened frames and the time-first view of
         ODEConvGRU.py:63-68, as one fused launch where that applies."""
-        if self._fused(frames):
+        how = self._fused(frames)
+        if how == 1:
             return hip_ops.frame_encode(self.encoder, frames)
+        if how == 2:
+            return hip_ops.frame_encode_autograd(self.encoder, frames)
         b, t, c, h, w = frames.size()
         enc = self.encoder(frames.view(b * t, c, h, w))
         _, c_, h_, w_ = enc.size()
@@ -71,8 +80,11 @@ class Decoder(nn.Module):
     def decode_sigmoid(self, sol_y):
         """sol_y (T,B,C,h,w) -> sigmoid(decoder(sol_y)) as (T,B,c,4h,4w) (ODEConvGRU.py:84-86), one fused launch where that applies."""
         wants_grad = torch.is_grad_enabled() and (sol_y.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if sol_y.is_cuda and not wants_grad and tuple(sol_y.shape[-2:]) == (16, 16) and hip_ops.frame_decoder_supported(self.decoder):
-            return hip_ops.frame_decode(self.decoder, sol_y, True)
+        if sol_y.is_cuda and tuple(sol_y.shape[-2:]) == (16, 16) and hip_ops.frame_decoder_supported(self.decoder):
+            if not wants_grad:
+                return hip_ops.frame_decode(self.decoder, sol_y, True)
+            if hip_ops.codec_backward_enabled() and hip_ops.frame_decoder_backward_supported(self.decoder):
+                return hip_ops.frame_decode_autograd(self.decoder, sol_y, True)
         t, b, c, h, w = sol_y.size()
         pred = torch.sigmoid(self.decoder(sol_y.view(b * t, c, h, w)))
         _, c3, h3, w3 = pred.size()

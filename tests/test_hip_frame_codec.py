@@ -108,7 +108,9 @@ def test_parameter_updates_refresh_the_pack(cuda):
 
 
 @pytest.mark.gpu
-def test_model_inference_takes_the_fused_launches_and_training_does_not(cuda, monkeypatch):
+def test_model_takes_the_fused_launches_with_and_without_autograd(cuda, monkeypatch):
+    """inference: the two fused launches; under autograd: the same launches with their HIP backward (csrc/frame_codec_backward.hip);
+    with ODEHIP_CODEC_BACKWARD=0: the library convolutions, and the three agree"""
     import argparse
     from ode_rl_amd import hip_ops
     from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
@@ -122,14 +124,156 @@ def test_model_inference_takes_the_fused_launches_and_training_does_not(cuda, mo
     monkeypatch.setattr(hip_ops, "frame_encode", lambda *a: (calls.append("enc"), real_e(*a))[1])
     monkeypatch.setattr(hip_ops, "frame_decode", lambda *a: (calls.append("dec"), real_d(*a))[1])
     frames = procedural_tensor((2, 4, 1, 64, 64), 130, 0, 1).to(cuda)
+    truth = procedural_tensor((2, 4, 1, 64, 64), 133, 0, 1).to(cuda)
     ts = torch.tensor(np.arange(8) / 8).to(cuda)
     bd = {"observed_tp": ts[:4], "tp_to_predict": ts[4:]}
+    with torch.no_grad():   # the codec's LeakyReLUs off their kinks (_off_the_kinks): the two backward passes then use the same masks
+        e = model.conv_encoder.encoder
+        _off_the_kinks(e[2], torch.nn.functional.leaky_relu(_off_the_kinks(e[0], frames.view(8, 1, 64, 64)), 0.2))
+        mu, _ = model.ode_convgru_cell(model.conv_encoder.encode_time_first(frames), ts[:4])
+        _off_the_kinks(model.conv_decoder.decoder[0], model.diffeq_solver(mu, ts[4:]).reshape(8, 64, 16, 16))
+    calls.clear()
     with torch.no_grad():
         fused = model(frames, bd)
     assert calls == ["enc", "dec"]
-    pred = model(frames, bd)            # under autograd: the library convolutions, differentiable
-    assert calls == ["enc", "dec"] and pred.requires_grad
-    _close("codec.model.fused_vs_library", fused, pred, rel=5e-6)
+
+    def step():
+        model.zero_grad()
+        pred = model(frames, bd)
+        model.get_loss(pred, truth).backward()
+        return pred.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    pred_hip, g_hip = step()            # under autograd: the fused launches again, now with their own backward
+    assert calls == ["enc", "dec", "enc", "dec"]
+    assert torch.equal(pred_hip, fused)
+    monkeypatch.setenv("ODEHIP_CODEC_BACKWARD", "0")
+    pred_lib, g_lib = step()            # the library convolutions, differentiable through torch
+    assert calls == ["enc", "dec", "enc", "dec"]
+    _close("codec.model.fused_vs_library", fused, pred_lib, rel=5e-6)
+    assert set(g_hip) == set(g_lib)
+    worst = {k: rel_l2(g_hip[k], g_lib[k]) for k in g_hip}
+    record("codec.model.grads_hip_vs_library", max(worst.values()))
+    # 1e-3 as tests/test_hip_train_end_to_end.py: the ReLUs of the two dynamics see inputs that differ in the last bits
+    assert max(worst.values()) <= 1e-3, {k: v for k, v in worst.items() if v > 1e-3}
+
+
+def _off_the_kinks(conv, x, margin=1.25):
+    """Give `conv` a bias that keeps every pre-activation of the following LeakyReLU away from zero on input x (channel c entirely
+    positive or entirely negative, alternating): the mask of the backward pass is then the same in fp32, in fp64 and in the
+    library, and a comparison of gradients is not decided by which elements of a near-zero pre-activation flip.  Both branches of
+    the LeakyReLU stay exercised.  Returns conv(x) with the new bias."""
+    with torch.no_grad():
+        conv.bias.zero_()
+        pre = conv(x)
+        top = float(pre.abs().max())
+        sign = torch.tensor([1.0 if c % 2 == 0 else -1.0 for c in range(conv.bias.numel())], dtype=pre.dtype, device=pre.device)
+        conv.bias.copy_(sign * margin * top)
+        return pre + conv.bias.view(1, -1, 1, 1)
+
+
+def _codec_reference_grads(enc, dec, frames, z, g_enc, g_pred):
+    """fp64 torch on the CPU: the gradients the two HIP backward calls must reproduce"""
+    enc64, dec64 = _copy64(enc), _copy64(dec)
+    b, t, c = frames.shape[:3]
+    lat = z.shape[2]
+    out = enc64(frames.double().view(b * t, c, 64, 64)).view(b, t, lat, 16, 16).permute(1, 0, 2, 3, 4)
+    out.backward(g_enc.double())
+    z64 = z.double().requires_grad_(True)
+    pred = torch.sigmoid(dec64(z64.view(-1, lat, 16, 16))).view(g_pred.shape)
+    pred.backward(g_pred.double())
+    return ({k: p.grad for k, p in enc64.named_parameters()}, {k: p.grad for k, p in dec64.named_parameters()}, z64.grad)
+
+
+def _copy64(m):
+    import copy
+    return copy.deepcopy(m).double()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lat,b,t,natural", [(64, 2, 3, True), (32, 1, 2, True), (64, 23, 13, False), (32, 40, 8, False), (64, 2, 4, False)])
+def test_backward_matches_fp64_autograd(cuda, lat, b, t, natural):
+    """odehip_frame_encode_backward / odehip_frame_decode_backward against torch.autograd in fp64 through the same modules (the
+    reference's Encoder / Decoder structure, models/ODEConvGRU.py:101-140): every parameter's gradient and the latents'.
+    (64, 23, 13) and (32, 40, 8) are 299 / 320 images: more than one unit per persistent workgroup, and an odd count.
+    `natural`: procedural weights as they come (these two small cases have no pre-activation within rounding of a LeakyReLU kink;
+    with 8 images one of 262144 already has, and fp32 and fp64 then disagree on ONE mask -- 3e-4 of the gradient); otherwise the
+    biases keep every pre-activation off the kinks (_off_the_kinks).
+    Tolerance 2e-5 relative L2 (fp32 sums over up to 320 x 1024 terms against fp64; observed ~1e-6)."""
+    from ode_rl_amd import hip_ops
+    enc, dec = _encoder(1, lat, 51), _decoder(lat, 1, 52)
+    frames = procedural_tensor((b, t, 1, 64, 64), 151, -1, 1)
+    z = procedural_tensor((t, b, lat, 16, 16), 152, -2, 2)
+    g_enc = procedural_tensor((t, b, lat, 16, 16), 153, -1, 1)
+    g_pred = procedural_tensor((t, b, 1, 64, 64), 154, -1, 1)
+    if not natural:
+        a1 = torch.nn.functional.leaky_relu(_off_the_kinks(enc.encoder[0], frames.view(b * t, 1, 64, 64)), 0.2)
+        _off_the_kinks(enc.encoder[2], a1)
+        _off_the_kinks(dec.decoder[0], z.view(t * b, lat, 16, 16))
+    want_e, want_d, want_z = _codec_reference_grads(enc, dec, frames, z, g_enc, g_pred)
+    enc, dec = enc.to(cuda), dec.to(cuda)
+    out = hip_ops.frame_encode_autograd(enc.encoder, frames.to(cuda))
+    assert out.requires_grad
+    out.backward(g_enc.to(cuda))
+    zc = z.to(cuda).requires_grad_(True)
+    pred = hip_ops.frame_decode_autograd(dec.decoder, zc, True)
+    pred.backward(g_pred.to(cuda))
+    tag = f"codec.bwd.{lat}.{b}x{t}"
+    for k, p in enc.named_parameters():
+        assert p.grad is not None and record(f"{tag}.enc.{k}", rel_l2(p.grad, want_e[k].float())) <= 2e-5, k
+    for k, p in dec.named_parameters():
+        # decoder.2.bias is ONE number: the sum of up to 1.3 million gradient values of both signs (|sum| ~ 1e-5 of sum |.|)
+        assert p.grad is not None and record(f"{tag}.dec.{k}", rel_l2(p.grad, want_d[k].float())) <= (1e-4 if k == "decoder.2.bias" else 2e-5), k
+    assert record(f"{tag}.dec.latents", rel_l2(zc.grad, want_z.float())) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_backward_is_bitwise_reproducible_and_handles_kinks(cuda):
+    """two runs give identical bits (fixed-order slab sums, no atomics); inputs with exact zeros at the LeakyReLUs (zero frames, zero
+    latents, zero biases) take the slope branch exactly as torch does (x > 0 ? 1 : slope)"""
+    from ode_rl_amd import hip_ops
+    enc, dec = _encoder(1, 64, 61), _decoder(64, 1, 62)
+    with torch.no_grad():
+        for m in (enc.encoder[0], enc.encoder[2], dec.decoder[0], dec.decoder[2]):
+            m.bias.zero_()
+    b, t = 3, 2
+    frames = procedural_tensor((b, t, 1, 64, 64), 161, -1, 1)
+    frames[0, 1].zero_()
+    z = procedural_tensor((t, b, 64, 16, 16), 162, -2, 2)
+    z[1, 2].zero_()
+    g_enc = procedural_tensor((t, b, 64, 16, 16), 163, -1, 1)
+    g_pred = procedural_tensor((t, b, 1, 64, 64), 164, -1, 1)
+    want_e, want_d, want_z = _codec_reference_grads(enc, dec, frames, z, g_enc, g_pred)
+    enc, dec = enc.to(cuda), dec.to(cuda)
+
+    def run():
+        enc.zero_grad(); dec.zero_grad()
+        hip_ops.frame_encode_autograd(enc.encoder, frames.to(cuda)).backward(g_enc.to(cuda))
+        zc = z.to(cuda).requires_grad_(True)
+        hip_ops.frame_decode_autograd(dec.decoder, zc, True).backward(g_pred.to(cuda))
+        return [p.grad.clone() for p in enc.parameters()] + [p.grad.clone() for p in dec.parameters()] + [zc.grad.clone()]
+    a, b2 = run(), run()
+    assert all(torch.equal(u, v) for u, v in zip(a, b2))
+    want = [want_e[k] for k, _ in enc.named_parameters()] + [want_d[k] for k, _ in dec.named_parameters()] + [want_z]
+    for got, w in zip(a, want):
+        assert rel_l2(got, w.float()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_backward_rejects_what_it_does_not_implement(cuda):
+    from ode_rl_amd import hip_ops
+    enc3, dec3 = _encoder(3, 64, 1).to(cuda), _decoder(64, 3, 1).to(cuda)
+    enc128 = _encoder(1, 128, 1).to(cuda)
+    assert not hip_ops.frame_encoder_backward_supported(enc3.encoder) and not hip_ops.frame_decoder_backward_supported(dec3.decoder)
+    assert not hip_ops.frame_encoder_backward_supported(enc128.encoder)
+    with pytest.raises(ValueError):
+        hip_ops.frame_encode_autograd(enc3.encoder, torch.zeros(1, 1, 3, 64, 64, device=cuda))
+    with pytest.raises(ValueError):
+        hip_ops.frame_decode_autograd(dec3.decoder, torch.zeros(1, 64, 16, 16, device=cuda), True)
+    enc = _encoder(1, 64, 1).to(cuda)
+    with pytest.raises(ValueError):
+        hip_ops.frame_encode_autograd(enc.encoder, torch.zeros(1, 1, 1, 64, 64, device=cuda, requires_grad=True))
+    # a model with three frame channels trains through the library path, silently and correctly
+    pred = dec3(torch.zeros(2, 64, 16, 16, device=cuda, requires_grad=True))
+    assert pred.requires_grad
 
 
 @pytest.mark.gpu

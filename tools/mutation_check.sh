@@ -23,8 +23,11 @@ SED[adjoint_dense_weight]='s/  const double C2 = d7 - 4.0 \* d1 - 5.0 \* b + 16.
 SED[walk16_out_transform]='s/      val = pk_sub(pk_sub(\*(const f32x4\*)(x + 1024) + bias4, \*(const f32x4\*)(x + 2048)), \*(const f32x4\*)(x + 3072));/      val = pk_sub(pk_sub(*(const f32x4*)(x + 1024) + bias4, *(const f32x4*)(x + 3072)), *(const f32x4*)(x + 2048)) * 1.001f;/'   # 16-workgroup walk: second half of the output transform
 SED[saving_slot_offset]='s/  fa.off_y1 = (long long)(6 \* BL.st);/  fa.off_y1 = (long long)(5 * BL.st);/'                # saving forward: y1 read from the wrong stage input of the slot
 SED[wgrad_wino5_bt]='s/  out\[0\] = w5_fma2(4.0f, in\[0\], w5_fma2(-5.0f, in\[2\], in\[4\]));/  out[0] = w5_fma2(4.0f, in[0], w5_fma2(-4.0f, in[2], in[4]));/'   # Winograd F(2x2,5x5) weight gradient: B^T row 0
+SED[codec_bwd_dec_tap]='s/          const int pa = (ky \& 1) ^ 1, ta = ky >> 1, pb = (kx \& 1) ^ 1, tb = kx >> 1;/          const int pa = (ky \& 1) ^ 1, ta = ky >> 1, pb = (kx \& 1), tb = kx >> 1;/'   # decoder backward: column parity of the second layer'"'"'s weights
+SED[codec_bwd_enc_dx]='s/        const int dx = kx == 0 ? 1 : 0;/        const int dx = kx == 2 ? 1 : 0;/'   # encoder backward: which odd-column tap reads the next source column
+SED[codec_bwd_dw1_centre]='s/        const float\* const bp = gm + ((2 \* iy + ky) \* kMW + 8 \* kq + kx) \* kMPix + nn;/        const float* const bp = gm + ((2 * iy + ky) * kMW + 8 * kq + kx + 1) * kMPix + nn;/'   # decoder backward: dW1 operand shifted by one column
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle"
+TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
@@ -43,7 +46,7 @@ build)
     echo "built $m"
   done ;;
 run)
-  # MUT_ONLY="name name ...": only those mutants, appended to the summary (a GPU lease is too short for all sixteen in one go)
+  # MUT_ONLY="name name ...": only those mutants, appended to the summary (a GPU lease is too short for all nineteen in one go)
   out=$ROOT/gpurun_out/mutation_check.txt
   cd "$ROOT"
   bad=0
