@@ -41,16 +41,17 @@ constexpr int kMidW = kHalf + 1;
 
 // Encoder, stage 0: one frame `src` (in_ch, 64, 64) -> img [in_ch][65][65] floats with its zero border; the zero border of
 // mid [quad 4][33][33] x 16 B.  No barrier inside.
+template <int THREADS = kCodecThreads>
 __device__ __forceinline__ void enc_stage_frame(const float* __restrict__ src, int in_ch, float* img, f32x4* mid, int tid) {
-  for (int i = tid; i < in_ch * (2 * kImgW - 1); i += kCodecThreads) {
+  for (int i = tid; i < in_ch * (2 * kImgW - 1); i += THREADS) {
     const int ic = i / (2 * kImgW - 1), e = i - ic * (2 * kImgW - 1);
     img[(size_t)ic * kImgW * kImgW + (e < kImgW ? e : (e - kImgW + 1) * kImgW)] = 0.0f;
   }
-  for (int i = tid; i < 4 * (2 * kMidW - 1); i += kCodecThreads) {
+  for (int i = tid; i < 4 * (2 * kMidW - 1); i += THREADS) {
     const int q = i / (2 * kMidW - 1), e = i - q * (2 * kMidW - 1);
     mid[q * kMidW * kMidW + (e < kMidW ? e : (e - kMidW + 1) * kMidW)] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int i = tid; i < in_ch * kFrame * kFrame / 4; i += kCodecThreads) {
+  for (int i = tid; i < in_ch * kFrame * kFrame / 4; i += THREADS) {
     const int ic = i / (kFrame * kFrame / 4), e = i - ic * (kFrame * kFrame / 4), r = e / (kFrame / 4), c4 = e - r * (kFrame / 4);
     const f32x4 v = *(const f32x4*)(src + (size_t)i * 4);
     float* d = img + (size_t)ic * kImgW * kImgW + (r + 1) * kImgW + 4 * c4 + 1;
@@ -60,11 +61,12 @@ __device__ __forceinline__ void enc_stage_frame(const float* __restrict__ src, i
 
 // Encoder, stage 1: Conv2d(in_ch, 16, 3, 2, 1) + LeakyReLU on the VALU, img -> mid: 4 output pixels per thread, all 16 channels.
 // `pack` = the encoder pack (w1, b1 in front).  Needs a barrier before (img complete) and after.
+template <int THREADS = kCodecThreads>
 __device__ __forceinline__ void enc_conv1_to_lds(const float* __restrict__ pack, int in_ch, float slope, const float* img, f32x4* mid, int tid) {
   typedef const __attribute__((address_space(4))) float ConstF;  // uniform reads of the small weights: scalar loads
   ConstF* const pk = (ConstF*)pack;
-  for (int s = 0; s < kHalf * kHalf / kCodecThreads; ++s) {
-    const int p = tid + s * kCodecThreads, oy = p / kHalf, ox = p - oy * kHalf;
+  for (int s = 0; s < kHalf * kHalf / THREADS; ++s) {
+    const int p = tid + s * THREADS, oy = p / kHalf, ox = p - oy * kHalf;
     float acc[kEncMid];
 #pragma unroll
     for (int c = 0; c < kEncMid; ++c) acc[c] = pk[enc_off_b1(in_ch) + c];

@@ -359,20 +359,24 @@ __global__ void pack_a2t_kernel(const float* __restrict__ w2, int out_ch, float*
   }
 }
 
+constexpr int kEncBwdThreads = 512;  // 8 waves, two per SIMD: one wave's LDS / global latencies are covered by the other's MFMAs
+
 template <int COB>  // out_ch / 16
-__global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(const EncBwdArgs a) {
+__global__ __launch_bounds__(kEncBwdThreads, 1) void frame_encode_bwd_kernel(const EncBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int out_ch = COB * 16, NT = out_ch / 4;
+  constexpr int RG = 8 / COB, ROWS = 16 / RG;  // dW2: wave = (channel block, one of RG groups of ROWS output rows)
   constexpr int kImgBytes = (kImgW * kImgW * 4 + 15) & ~15;
   float* const img = (float*)smem;
   f32x4* const mid = (f32x4*)(smem + kImgBytes);
   float* const g2 = (float*)(mid + 4 * kMidW * kMidW);  // [co][260]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nn = lane & 15, kq = lane >> 4;
+  const int cb = wave % COB, rg = wave / COB;
 
-  f32x4 acc1[9];            // dW2: this wave's output-channel block (wave < COB), per tap
+  f32x4 acc1[9];            // dW2: output-channel block cb, rows of group rg, per tap
   float aw1[9][4], ab1[4];  // dW1 / db1 partials of channels 4 kq + i
-  float ab2[COB * 4];       // db2 partials of channels wave + 4 k
+  float ab2[COB * 2];       // db2 partials of channels wave + 8 k
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -382,18 +386,18 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
 #pragma unroll
   for (int i = 0; i < 4; ++i) ab1[i] = 0.0f;
 #pragma unroll
-  for (int k = 0; k < COB * 4; ++k) ab2[k] = 0.0f;
+  for (int k = 0; k < COB * 2; ++k) ab2[k] = 0.0f;
 
   const int n_units = a.batch * a.n_frames;
   for (int f = blockIdx.x; f < n_units; f += gridDim.x) {
     const int b = f / a.n_frames, t = f - b * a.n_frames;
     if (f != (int)blockIdx.x) __syncthreads();
-    enc_stage_frame(a.frames + (size_t)f * kFrame * kFrame, 1, img, mid, tid);
+    enc_stage_frame<kEncBwdThreads>(a.frames + (size_t)f * kFrame * kFrame, 1, img, mid, tid);
     {
       const size_t base = ((size_t)t * a.batch + b) * out_ch * 256;
 #pragma unroll
-      for (int k = 0; k < COB * 4; ++k) {
-        const int i = tid + k * kCodecThreads, co = i >> 6, e = i & 63;  // co = wave + 4 k
+      for (int k = 0; k < COB * 2; ++k) {
+        const int i = tid + k * kEncBwdThreads, co = i >> 6, e = i & 63;  // co = wave + 8 k
         f32x4 g = *(const f32x4*)(a.g_out + base + (size_t)co * 256 + 4 * e);
         const f32x4 o = *(const f32x4*)(a.out + base + (size_t)co * 256 + 4 * e);
         g.x *= o.x > 0.0f ? 1.0f : a.slope;
@@ -405,15 +409,15 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
       }
     }
     __syncthreads();
-    enc_conv1_to_lds(a.pack + opaque_zero(), 1, a.slope, img, mid, tid);
+    enc_conv1_to_lds<kEncBwdThreads>(a.pack + opaque_zero(), 1, a.slope, img, mid, tid);
     __syncthreads();
 
     // ---- dW2[co][ci][ky][kx] += sum_{oy, ox} g2[co][oy][ox] act[ci][2 oy - 1 + ky][2 ox - 1 + kx]: k = pixels, a row per 4 MFMAs
-    if (wave < COB) {
+    {
       const float* const mf = (const float*)mid + ((nn >> 2) * kMidW * kMidW) * 4 + (nn & 3);
 #pragma unroll 1
-      for (int oy = 0; oy < 16; ++oy) {
-        const f32x4 af = *(const f32x4*)(g2 + (16 * wave + nn) * kG2Stride + oy * 16 + 4 * kq);
+      for (int oy = rg * ROWS; oy < (rg + 1) * ROWS; ++oy) {
+        const f32x4 af = *(const f32x4*)(g2 + (16 * cb + nn) * kG2Stride + oy * 16 + 4 * kq);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int ky = tap / 3, kx = tap % 3;
@@ -426,12 +430,12 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
       }
     }
     // ---- d act[ci][my][mx] = sum_{co, (ky, kx): my = 2 oy - 1 + ky, mx = 2 ox - 1 + kx} g2[co][oy][ox] w2[co][ci][ky][kx], output-
-    // stationary: this wave owns rows 8 wave .. 8 wave + 7; block (row, column parity pb) = the 16 pixels mx = 2 b + pb; k = channels
+    // stationary: this wave owns rows 4 wave .. 4 wave + 3; block (row, column parity pb) = the 16 pixels mx = 2 b + pb; k = channels
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {  // two passes (8 blocks of accumulators each): even columns (kx = 1), odd columns (kx = 0, 2)
-      f32x4 acc2[8];
+    for (int pb = 0; pb < 2; ++pb) {  // two passes (4 blocks of accumulators each): even columns (kx = 1), odd columns (kx = 0, 2)
+      f32x4 acc2[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap % 3;
@@ -443,8 +447,8 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
         const int dx = kx == 0 ? 1 : 0;
         const bool col_ok = nn + dx < 16;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int oy = 4 * wave + rr + (ky == 0 ? 1 : 0);
+        for (int rr = 0; rr < 2; ++rr) {
+          const int oy = 2 * wave + rr + (ky == 0 ? 1 : 0);
           const int mrow = ky == 1 ? 2 * rr : 2 * rr + 1;
           if (oy < 16) {  // wave-uniform
             const float* const bp = g2 + (4 * kq) * kG2Stride + oy * 16 + nn + dx;
@@ -458,8 +462,8 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
       }
       // ---- mask of the first LeakyReLU, then dW1[c][ky][kx] += g[c][my][mx] frame[2 my - 1 + ky][2 mx - 1 + kx], db1[c] += g
 #pragma unroll
-      for (int mrow = 0; mrow < 8; ++mrow) {
-        const int my = 8 * wave + mrow, mx = 2 * nn + pb;
+      for (int mrow = 0; mrow < 4; ++mrow) {
+        const int my = 4 * wave + mrow, mx = 2 * nn + pb;
         const f32x4 mv = mid[(kq * kMidW + my + 1) * kMidW + mx + 1];
         f32x4 g = acc2[mrow];
         g.x *= mv.x > 0.0f ? 1.0f : a.slope;
@@ -478,21 +482,32 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
       }
     }
   }
-  // ---- the slab
+  // ---- the slab.  dW2: the RG row groups of a channel block through LDS (everything in LDS is dead now)
   float* const slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
-  if (wave < COB) {
+  __syncthreads();
+  float* const red2 = (float*)smem;  // [rg - 1][cb][tap 9][lane 64] x 4 floats
+  if (rg > 0) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) slab[((size_t)(16 * wave + 4 * kq + i) * kEncMid + nn) * 9 + tap] = acc1[tap][i];
-  }
-#pragma unroll
-  for (int k = 0; k < COB * 4; ++k) {
-    const float s = wave_sum(ab2[k]);
-    if (lane == 0) slab[out_ch * 144 + wave + 4 * k] = s;
+    for (int tap = 0; tap < 9; ++tap) *(f32x4*)(red2 + ((((rg - 1) * COB + cb) * 9 + tap) * 64 + lane) * 4) = acc1[tap];
   }
   __syncthreads();
-  float* const red = (float*)smem;  // [wave 4][kq 4][40]
+  if (rg == 0) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 v = acc1[tap];
+#pragma unroll
+      for (int r = 1; r < RG; ++r) v += *(const f32x4*)(red2 + ((((r - 1) * COB + cb) * 9 + tap) * 64 + lane) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slab[((size_t)(16 * cb + 4 * kq + i) * kEncMid + nn) * 9 + tap] = v[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < COB * 2; ++k) {
+    const float s = wave_sum(ab2[k]);
+    if (lane == 0) slab[out_ch * 144 + wave + 8 * k] = s;
+  }
+  __syncthreads();
+  float* const red = (float*)smem;  // [wave 8][kq 4][40]
 #pragma unroll
   for (int tap = 0; tap < 10; ++tap)
 #pragma unroll
@@ -508,7 +523,9 @@ __global__ __launch_bounds__(kCodecThreads, 1) void frame_encode_bwd_kernel(cons
   if (tid < 160) {
     const int tap = tid / 16, c = tid % 16;  // tap 9 = the bias
     const int at = (c >> 2) * 40 + tap * 4 + (c & 3);
-    const float s = (red[at] + red[160 + at]) + (red[320 + at] + red[480 + at]);
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w * 160 + at];
     if (tap < 9) slab[out_ch * 145 + c * 9 + tap] = s;
     else slab[out_ch * 145 + 144 + c] = s;
   }
@@ -628,7 +645,7 @@ extern "C" int odehip_frame_encode_backward(const float* pack, const float* w2, 
       ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)frame_encode_bwd_kernel<COB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       attr[slot] = true;                                                                                                      \
     }                                                                                                                         \
-    hipLaunchKernelGGL(frame_encode_bwd_kernel<COB>, dim3(p), dim3(kCodecThreads), lds, stream, e);                           \
+    hipLaunchKernelGGL(frame_encode_bwd_kernel<COB>, dim3(p), dim3(kEncBwdThreads), lds, stream, e);                           \
   }
   if (out_ch == 32) ODEHIP_ENCB_LAUNCH(2, 0)
   else ODEHIP_ENCB_LAUNCH(4, 1)
