@@ -223,7 +223,7 @@ def model_context(a, dev, T, method=None):
             return m(frames, bd)
 
     def train():
-        optim.zero_grad(set_to_none=False)
+        optim.zero_grad()   # torch 2 default (set_to_none=True): what the reference's `optimizer.zero_grad()` (train_test.py:176) does today
         m.get_loss(m(frames, bd), truth).backward()
         optim.step()
 

@@ -84,6 +84,16 @@ int odehip_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int 
  * Winograd kernel.  Optional: a conv with w_wino == NULL runs the direct kernel. */
 size_t odehip_winograd_weight_floats(int cout, int cin);
 int odehip_pack_conv_weight_winograd(const float* w_oihw, float* w_wino, int cout, int cin, int transpose_flip, void* stream);
+/* Several of the two packs above in ONE launch (a training step repacks every weight tensor after the optimizer's update).
+ * kind 0 = odehip_pack_conv_weight (cout, cin, ks, transpose_flip), kind 1 = odehip_pack_conv_weight_winograd (ks must be 3),
+ * kind 2 = odehip_pack_conv_weight_winograd5 (ks must be 5); the results are identical to those calls'. */
+#define ODEHIP_MAX_PACK_JOBS 32
+typedef struct odehip_pack_job {
+  const float* w; /* (cout, cin, ks, ks) as nn.Conv2d holds it */
+  float* out;
+  int cout, cin, ks, kind, transpose_flip;
+} odehip_pack_job;
+int odehip_pack_conv_weights(const odehip_pack_job* jobs, int n_jobs, void* stream);
 /* bf16 A-operand image of a 3x3 weight (round to nearest even): cout % 32 == 0, cin % 16 == 0, cin <= 128 is what the
  * bf16 kernel serves; odehip_bf16_weight_bytes(cout, cin) bytes.  transpose_flip as odehip_pack_conv_weight. */
 /* Winograd F(2x2,5x5) form of a 5x5 weight (conv_wino5.hip): U = G g G^T for the points 0, +-1, +-2, inf; cout % 32 == 0,
@@ -432,10 +442,16 @@ int odehip_frame_decode(const float* pack, const float* latents, int n_images, i
  * 16) and pred (N, 1, 64, 64) = the forward's input and output, g_out = dL/d pred (sigmoid_applied: pred is after the sigmoid and
  * its derivative pred (1 - pred) is applied here).  Out: g_latents (N, in_ch, 16, 16), dw1 (in_ch, 32, 4, 4), db1 (32), dw2 (32, 1,
  * 4, 4), db2 (1). */
+/* odehip_frame_decode_train = odehip_frame_decode that also writes the 32-channel intermediate (after its LeakyReLU) to mid_save
+ * (n_images * 32 * 32 * 32 floats, channel quads: [N][8][32][32] x 4; may be NULL): handed to the backward as mid_saved it replaces the
+ * recomputation there (mid_saved NULL: recomputed from the latents, nothing but inputs and outputs kept). */
+int odehip_frame_decode_train(const float* pack, const float* latents, int n_images, int in_ch, int out_ch, float negative_slope,
+                              int apply_sigmoid, float* out, float* mid_save, void* stream);
 size_t odehip_frame_decode_backward_workspace_floats(int n_images, int in_ch, int out_ch);
-int odehip_frame_decode_backward(const float* pack, const float* w1, const float* latents, const float* pred, const float* g_out,
-                                 int n_images, int in_ch, int out_ch, float negative_slope, int sigmoid_applied, float* g_latents,
-                                 float* dw1, float* db1, float* dw2, float* db2, float* workspace, size_t workspace_floats, void* stream);
+int odehip_frame_decode_backward(const float* pack, const float* w1, const float* latents, const float* mid_saved, const float* pred,
+                                 const float* g_out, int n_images, int in_ch, int out_ch, float negative_slope, int sigmoid_applied,
+                                 float* g_latents, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                                 size_t workspace_floats, void* stream);
 /* Encoder: pack = the forward's pack, w2 = the second Conv2d's weight (out_ch, 16, 3, 3); frames (B, T, 1, 64, 64),
  * out_time_first = the forward's result (T, B, out_ch, 16, 16), g_out_time_first = dL/d of it in the same layout.  The frames
  * receive no gradient.  Out: dw1 (16, 1, 3, 3), db1 (16), dw2 (out_ch, 16, 3, 3), db2 (out_ch). */

@@ -29,6 +29,14 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+MAX_PACK_JOBS = 32
+
+
+class PackJob(ctypes.Structure):   # odehip_pack_job
+    _fields_ = [("w", ctypes.c_void_p), ("out", ctypes.c_void_p), ("cout", ctypes.c_int), ("cin", ctypes.c_int), ("ks", ctypes.c_int),
+                ("kind", ctypes.c_int), ("transpose_flip", ctypes.c_int)]
+
+
 class ConvStack(ctypes.Structure):
     _fields_ = [
         ("n_convs", ctypes.c_int), ("ks", ctypes.c_int),
@@ -116,7 +124,9 @@ SIGNATURES = {
     "odehip_frame_encode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
     "odehip_frame_decode_backward_workspace_floats": (ctypes.c_size_t, [ctypes.c_int] * 3),
-    "odehip_frame_decode_backward": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] +
+    "odehip_frame_decode_train": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "odehip_frame_decode_backward": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] +
                                      [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_frame_encode_backward_workspace_floats": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "odehip_frame_encode_backward": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float] +
@@ -139,6 +149,7 @@ SIGNATURES = {
     "odehip_pack_conv_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_winograd_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "odehip_pack_conv_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "odehip_pack_conv_weight_winograd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                         ctypes.c_int, ctypes.c_void_p]),
     "odehip_nchw_to_q4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -154,6 +154,8 @@ struct DecArgs {
   int n_images, in_ch, out_ch;
   float slope;
   int sigmoid;
+  float* mid_out;        // optional: [N][quad 8][32][32] x 4, the intermediate after its LeakyReLU (the training forward saves it for
+                         // frame_decode_bwd_mid_kernel, which would otherwise recompute it: 100 us of MFMA work against 25 us of stores)
 };
 
 // One workgroup per (image, quarter q of the output rows): output rows 16q .. 16q+15 need intermediate rows 8q-1 .. 8q+8, which
@@ -174,6 +176,13 @@ __global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_kernel(const De
   // ---- phases 0, 1: latent rows -> LDS, ConvTranspose2d(in_ch, 32, 4, 2, 1) + LeakyReLU on the MFMA -> mid (frame_codec.h)
   dec_mid_to_lds<G>(a.pack, a.latents + (size_t)n * in_ch * 256, q, a.slope, z, mid, tid, lane, wave);
   __syncthreads();
+  if (a.mid_out) {  // this workgroup's own eight rows 8q .. 8q+7 (local rows 1 .. 8), one pixel per thread
+    const int pr = tid >> 5, mx = tid & 31;
+    const float* const mp = mid + ((pr + 1) * kMW + mx + 1) * kMPix;
+    f32x4* const dst = (f32x4*)a.mid_out + (((size_t)n * 8) * kHalf + 8 * q + pr) * kHalf + mx;
+#pragma unroll
+    for (int cq = 0; cq < 8; ++cq) dst[(size_t)cq * kHalf * kHalf] = *(const f32x4*)(mp + 4 * cq);
+  }
 
   // ---- phase 2: ConvTranspose2d(32, out_ch, 4, 2, 1) [+ sigmoid] on the VALU.  This wave: output pixels (16q + 2 il + pa,
   // 2 j + pb), il = 0..7, j = 0..31: four per lane.  Weights of its parity: [tap 4][o][ci 32], wave-uniform.
@@ -301,8 +310,16 @@ extern "C" int odehip_frame_encode(const float* pack, const float* frames, int b
   return ODEHIP_OK;
 }
 
+extern "C" int odehip_frame_decode_train(const float* pack, const float* latents, int n_images, int in_ch, int out_ch,
+                                         float negative_slope, int apply_sigmoid, float* out, float* mid_save, void* stream);
+
 extern "C" int odehip_frame_decode(const float* pack, const float* latents, int n_images, int in_ch, int out_ch, float negative_slope,
                                    int apply_sigmoid, float* out, void* stream) {
+  return odehip_frame_decode_train(pack, latents, n_images, in_ch, out_ch, negative_slope, apply_sigmoid, out, nullptr, stream);
+}
+
+extern "C" int odehip_frame_decode_train(const float* pack, const float* latents, int n_images, int in_ch, int out_ch,
+                                         float negative_slope, int apply_sigmoid, float* out, float* mid_save, void* stream) {
   ODEHIP_REQUIRE(pack && latents && out, "frame_decode: null pointer argument");
   ODEHIP_REQUIRE(n_images > 0, "frame_decode: n_images must be positive");
   int rc = check_decoder_shape("frame_decode", in_ch, out_ch);
@@ -310,6 +327,7 @@ extern "C" int odehip_frame_decode(const float* pack, const float* latents, int 
   DecArgs a;
   a.pack = pack; a.latents = latents; a.out = out; a.n_images = n_images; a.in_ch = in_ch; a.out_ch = out_ch; a.slope = negative_slope;
   a.sigmoid = apply_sigmoid;
+  a.mid_out = mid_save;
   const size_t lds = dec_lds_bytes(in_ch);
   const dim3 grid((unsigned)n_images * 4);
   static bool attr[3] = {false, false, false};

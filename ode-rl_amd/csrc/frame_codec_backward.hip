@@ -83,6 +83,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct DecBwdMidArgs {
   const float* pack;     // the forward's decoder pack
   const float* latents;  // (N, in_ch, 16, 16)
+  const float* mid;      // SAVED: [N][quad 8][32][32] x 4, the intermediate after its LeakyReLU as odehip_frame_decode_train saved it
   const float* pred;     // (N, 1, 64, 64): the forward's output (after the sigmoid if `sigmoid`)
   const float* g_out;    // (N, 1, 64, 64): dL/d pred
   float* gmid;           // [N][quad 8][32][32] x 4: dL/d(intermediate before its LeakyReLU)
@@ -94,13 +95,17 @@ struct DecBwdMidArgs {
 constexpr int kGzW = 66;                 // g tile: rows 16q-1 .. 16q+16, columns -1 .. 64
 constexpr int kDecBwdSlab1 = 576;        // >= 513 floats
 
-template <int G>
+// SAVED: the intermediate comes from HBM (this unit's eight rows as an [8][32][36] LDS tile: 41 KiB with g, three workgroups per CU);
+// otherwise it is recomputed from the latents (z + [10][34][36] tile, two per CU).
+template <int G, bool SAVED>
 __global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_bwd_mid_kernel(const DecBwdMidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int in_ch = G * 16;
+  // pixel (row pr of the unit's eight, column mx) of the LDS tile: mid + pix0 + (pr * pixw + mx) * kMPix
+  constexpr int pixw = SAVED ? kHalf : kMW, pix0 = SAVED ? 0 : (kMW + 1) * kMPix;
   f32x4* const z = (f32x4*)smem;
-  float* const mid = (float*)(smem + (size_t)4 * G * kZRows * kZW * 16);
-  float* const gz = mid + kMRows * kMW * kMPix;
+  float* const mid = (float*)(smem + (SAVED ? (size_t)0 : (size_t)4 * G * kZRows * kZW * 16));
+  float* const gz = mid + (SAVED ? 8 * kHalf : kMRows * kMW) * kMPix;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m16 = lane & 15, kq = lane >> 4;
   CodecConstF* const w2 = (CodecConstF*)(a.pack + dec_off_w2(in_ch));  // [parity 4][tap 4][o = 1][ci 32]
@@ -122,7 +127,16 @@ __global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_bwd_mid_kernel(
       }
       gz[i] = v;
     }
-    dec_mid_to_lds<G>(a.pack, a.latents + (size_t)n * in_ch * 256, q, a.slope, z, mid, tid, lane, wave);
+    if (SAVED) {
+      const f32x4* const src = (const f32x4*)a.mid + (((size_t)n * 8) * kHalf + 8 * q) * kHalf;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {   // 8 quads x 256 pixels: element i = quad * 256 + pixel
+        const int i = tid + k * kCodecThreads;
+        *(f32x4*)(mid + (i & 255) * kMPix + 4 * (i >> 8)) = src[(size_t)(i >> 8) * kHalf * kHalf + (i & 255)];
+      }
+    } else {
+      dec_mid_to_lds<G>(a.pack, a.latents + (size_t)n * in_ch * 256, q, a.slope, z, mid, tid, lane, wave);
+    }
     __syncthreads();
 
     // ---- this thread's intermediate pixel (8q + pr, mx): gradient through the 4x4 window of g, mask, one write
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_bwd_mid_kernel(
 #pragma unroll
           for (int c = 0; c < kDecMid; ++c) gacc[c] = __builtin_fmaf(win[ky * 4 + kx], w[c], gacc[c]);
         }
-      const float* const mp = mid + ((pr + 1) * kMW + mx + 1) * kMPix;
+      const float* const mp = mid + pix0 + (pr * pixw + mx) * kMPix;
       f32x4* const dst = (f32x4*)a.gmid + (((size_t)n * 8) * kHalf + 8 * q + pr) * kHalf + mx;
 #pragma unroll
       for (int cq = 0; cq < 8; ++cq) {
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(kCodecThreads, 2) void frame_decode_bwd_mid_kernel(
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
       const int p = 4 * s + kq, pr = 2 * wave + (p >> 5), mx = p & 31;
-      const float* const mp = mid + ((pr + 1) * kMW + mx + 1) * kMPix + m16;
+      const float* const mp = mid + pix0 + (pr * pixw + mx) * kMPix + m16;
       const float bv = gz[(2 * pr + (m16 >> 2)) * kGzW + 2 * mx + (m16 & 3)];
       accw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[0], bv, accw[0], 0, 0, 0);
       accw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(mp[16], bv, accw[1], 0, 0, 0);
@@ -565,8 +579,8 @@ extern "C" size_t odehip_frame_decode_backward_workspace_floats(int n_images, in
          (size_t)n_workgroups(2LL * n_images, 1) * dec_slab2_floats(in_ch);
 }
 
-extern "C" int odehip_frame_decode_backward(const float* pack, const float* w1, const float* latents, const float* pred, const float* g_out,
-                                            int n_images, int in_ch, int out_ch, float negative_slope, int sigmoid_applied, float* g_latents,
+extern "C" int odehip_frame_decode_backward(const float* pack, const float* w1, const float* latents, const float* mid_saved,
+                                            const float* pred, const float* g_out, int n_images, int in_ch, int out_ch, float negative_slope, int sigmoid_applied, float* g_latents,
                                             float* dw1, float* db1, float* dw2, float* db2, float* workspace, size_t workspace_floats,
                                             void* stream_) {
   ODEHIP_REQUIRE(pack && w1 && latents && pred && g_out && g_latents && dw1 && db1 && dw2 && db2 && workspace,
@@ -586,21 +600,24 @@ extern "C" int odehip_frame_decode_backward(const float* pack, const float* w1, 
   hipLaunchKernelGGL(pack_a1t_kernel, dim3(64), dim3(256), 0, stream, w1, in_ch, a1t);
 
   DecBwdMidArgs m;
-  m.pack = pack; m.latents = latents; m.pred = pred; m.g_out = g_out; m.gmid = gmid; m.slabs = slabs1; m.n_images = n_images;
+  m.pack = pack; m.latents = latents; m.mid = mid_saved; m.pred = pred; m.g_out = g_out; m.gmid = gmid; m.slabs = slabs1; m.n_images = n_images;
   m.sigmoid = sigmoid_applied; m.slab_stride = kDecBwdSlab1; m.slope = negative_slope;
   DecBwdLatArgs l;
   l.a1t = a1t; l.latents = latents; l.gmid = gmid; l.g_latents = g_latents; l.slabs = slabs2; l.n_images = n_images; l.slab_stride = s2;
-  const size_t lds1 = (size_t)(in_ch / 4) * kZRows * kZW * 16 + (size_t)kMRows * kMW * kMPix * 4 + (size_t)18 * kGzW * 4;
+  const size_t lds1 = (mid_saved ? (size_t)8 * kHalf * kMPix * 4 : (size_t)(in_ch / 4) * kZRows * kZW * 16 + (size_t)kMRows * kMW * kMPix * 4) +
+                      (size_t)18 * kGzW * 4;
   const size_t lds2 = (size_t)18 * kMW * kMPix * 4 + (size_t)in_ch * kLatStride * 4;
   static bool attr[2] = {false, false};
 #define ODEHIP_DECB_LAUNCH(G, slot)                                                                                              \
   {                                                                                                                             \
     if (!attr[slot]) {                                                                                                          \
-      ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)frame_decode_bwd_mid_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)frame_decode_bwd_mid_kernel<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)frame_decode_bwd_mid_kernel<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)frame_decode_bwd_lat_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
       attr[slot] = true;                                                                                                        \
     }                                                                                                                           \
-    hipLaunchKernelGGL(frame_decode_bwd_mid_kernel<G>, dim3(p1), dim3(kCodecThreads), lds1, stream, m);                         \
+    if (mid_saved) hipLaunchKernelGGL((frame_decode_bwd_mid_kernel<G, true>), dim3(p1), dim3(kCodecThreads), lds1, stream, m);  \
+    else hipLaunchKernelGGL((frame_decode_bwd_mid_kernel<G, false>), dim3(p1), dim3(kCodecThreads), lds1, stream, m);           \
     hipLaunchKernelGGL(frame_decode_bwd_lat_kernel<G>, dim3(p2), dim3(kDecBwdThreads2), lds2, stream, l);                       \
   }
   if (in_ch == 32) ODEHIP_DECB_LAUNCH(2, 0)

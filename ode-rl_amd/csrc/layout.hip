@@ -2,7 +2,10 @@
 //
 //   NCHW (the reference's tensors, modules/DiffEqSolver.py:24-52)  <->  Q4 [b][c/4][pixel][4]
 //   OIHW conv weight (nn.Conv2d, helpers/utils.py:167-177)          ->  MFMA-ordered LDS image
+#include <string.h>
+
 #include "odehip_internal.h"
+#include "pack_elems.h"
 
 namespace odehip {
 
@@ -69,11 +72,8 @@ __global__ __launch_bounds__(256) void q4_to_nchw_kernel(const float* __restrict
 
 // packed[ct][m][tap][kq][i][s] = W[co = ct*32+i][ci = 8m+4kq+s][tap]      (transpose_flip == 0)
 //                              = W[co' = ci][ci' = co][taps-1-tap]        (dgrad weights)
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                          int cout, int cin, int taps, int transpose_flip,
-                                                          int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ void pack_weight_elem(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps,
+                                                 int transpose_flip, int idx) {
   int r = idx;
   const int s = r & 3; r >>= 2;
   const int i = r & 31; r >>= 5;
@@ -94,12 +94,17 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   out[idx] = v;
 }
 
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                          int cout, int cin, int taps, int transpose_flip,
+                                                          int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) pack_weight_elem(w, out, cout, cin, taps, transpose_flip, idx);
+}
+
 // Winograd F(2x2,3x3) weights U = G g G^T in the LDS image of conv_wino.hip:
 //   out[ct][c][xi][quad][i][s] = U_xi[co = ct*32+i][ci = 16c + 4quad + s],  xi = 4r + col
-__global__ __launch_bounds__(256) void pack_winograd_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
-                                                            int cin, int transpose_flip, int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ void pack_winograd_elem(const float* __restrict__ w, float* __restrict__ out, int cout, int cin,
+                                                   int transpose_flip, int idx) {
   int r = idx;
   const int s = r & 3; r >>= 2;
   const int i = r & 31; r >>= 5;
@@ -125,6 +130,34 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float* __restr
   }
   const float uv = uc == 0 ? t[0] : (uc == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (uc == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
   out[idx] = ur == 3 ? -uv : uv;  // conv_wino.hip computes row 3 of B^T d with the opposite sign
+}
+
+__global__ __launch_bounds__(256) void pack_winograd_kernel(const float* __restrict__ w, float* __restrict__ out, int cout,
+                                                            int cin, int transpose_flip, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) pack_winograd_elem(w, out, cout, cin, transpose_flip, idx);
+}
+
+// every pack of a conv stack in ONE launch (a training step repacks ~50 weight tensors after the optimizer's update: as single
+// launches of 5 us each they were 0.3 ms of a 12 ms step)
+struct PackJobs {
+  odehip_pack_job job[ODEHIP_MAX_PACK_JOBS];
+  int start[ODEHIP_MAX_PACK_JOBS + 1];  // first element index of job j in the launch's index space (multiples of 256)
+  int n;
+};
+
+__global__ __launch_bounds__(256) void pack_many_kernel(const PackJobs p) {
+  const int blk = blockIdx.x * 256;
+  int j = 0;
+  while (j + 1 < p.n && blk >= p.start[j + 1]) ++j;  // block-uniform: job boundaries are multiples of the block size
+  const odehip_pack_job& q = p.job[j];
+  const int idx = blk - p.start[j] + threadIdx.x;
+  const int taps = q.ks * q.ks;
+  const int total = q.cout * q.cin * (q.kind == 1 ? 16 : (q.kind == 2 ? 36 : taps));
+  if (idx >= total) return;
+  if (q.kind == 1) pack_winograd_elem(q.w, q.out, q.cout, q.cin, q.transpose_flip, idx);
+  else if (q.kind == 2) pack_winograd5_elem(q.w, q.out, q.cout, q.cin, q.transpose_flip, idx);
+  else pack_weight_elem(q.w, q.out, q.cout, q.cin, taps, q.transpose_flip, idx);
 }
 
 }  // namespace odehip
@@ -158,6 +191,35 @@ extern "C" int odehip_pack_conv_weight(const float* w_oihw, float* w_packed, int
   const int total = cout * cin * ks * ks;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw,
                      w_packed, cout, cin, ks * ks, transpose_flip, total);
+  ODEHIP_CHECK_HIP(hipGetLastError());
+  return ODEHIP_OK;
+}
+
+extern "C" int odehip_pack_conv_weights(const odehip_pack_job* jobs, int n_jobs, void* stream) {
+  ODEHIP_REQUIRE(jobs && n_jobs > 0 && n_jobs <= ODEHIP_MAX_PACK_JOBS, "pack_conv_weights: 1..%d jobs (got %d)", ODEHIP_MAX_PACK_JOBS, n_jobs);
+  PackJobs p;
+  memset(&p, 0, sizeof(p));
+  p.n = n_jobs;
+  long long at = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const odehip_pack_job& q = jobs[j];
+    ODEHIP_REQUIRE(q.w && q.out, "pack_conv_weights: job %d: null pointer", j);
+    ODEHIP_REQUIRE(q.kind >= 0 && q.kind <= 2, "pack_conv_weights: job %d: kind %d (0: odehip_pack_conv_weight, 1: ..._winograd, 2: ..._winograd5)", j, q.kind);
+    ODEHIP_REQUIRE(q.cout > 0 && q.cout % 32 == 0, "pack_conv_weights: job %d: cout must be a multiple of 32 (got %d)", j, q.cout);
+    if (q.kind == 1) {
+      ODEHIP_REQUIRE(q.cin > 0 && q.cin % 16 == 0 && q.ks == 3, "pack_conv_weights: job %d: Winograd packs need 3x3 and cin %% 16 == 0", j);
+    } else {
+      ODEHIP_REQUIRE(q.cin > 0 && q.cin % 8 == 0, "pack_conv_weights: job %d: cin must be a multiple of 8 (got %d)", j, q.cin);
+      ODEHIP_REQUIRE(q.kind == 2 ? q.ks == 5 : (q.ks == 1 || q.ks == 3 || q.ks == 5), "pack_conv_weights: job %d: kernel size %d unsupported", j, q.ks);
+    }
+    p.job[j] = q;
+    p.start[j] = (int)at;
+    const long long total = (long long)q.cout * q.cin * (q.kind == 1 ? 16 : (q.kind == 2 ? 36 : q.ks * q.ks));
+    at += (total + 255) / 256 * 256;
+    ODEHIP_REQUIRE(at < (1LL << 31), "pack_conv_weights: too many elements in one call");
+  }
+  p.start[n_jobs] = (int)at;
+  hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)(at / 256)), dim3(256), 0, (hipStream_t)stream, p);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

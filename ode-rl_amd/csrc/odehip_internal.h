@@ -232,6 +232,9 @@ int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esp
                       hipStream_t stream);
 
 // a 64 x 64 tile of a 5x5 weight gradient in the Winograd F(2x2,5x5) domain (wgrad_wino5.hip); 1 = switched off
+// sum[i] = sum over k < n_slabs of slabs[k * stride + i], i < n_vals, in a fixed order (16 interleaved partial sums of 4 chains each,
+// 16-byte loads: bitwise reproducible).  stride and n_vals multiples of 4 floats, slabs and sum 16-byte aligned.  (wgrad.hip)
+void launch_slab_sum4(const float* slabs, int n_slabs, int stride, int n_vals, float* sum, hipStream_t stream);
 int launch_wgrad_wino5(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int cin_total,
                        int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias, hipStream_t stream);
 int launch_wgrad_tile_bf16_5x5(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db,

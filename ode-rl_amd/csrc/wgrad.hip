@@ -148,6 +148,37 @@ __global__ __launch_bounds__(256, 1) void wgrad64_kernel(const WgradPair* __rest
   }
 }
 
+// The slab sum of the Winograd-domain weight gradients (wgrad_wino.hip, wgrad_wino5.hip): 256 slabs of 144 - 256 KiB.  One block =
+// 64 float4 outputs x 16 slab groups; a thread adds its group's slabs in 4 independent chains of 16-byte loads (the first version --
+// 64 floats x 4 groups of 4-byte loads -- had 12 KiB in flight per CU and ran at 2.3 TB/s), the 16 partial sums through LDS.
+__global__ __launch_bounds__(1024) void slab_sum4_kernel(const f32x4* __restrict__ slabs, int n_slabs, int stride4, int n4, f32x4* __restrict__ sum) {
+  __shared__ f32x4 part[16][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
+  if (i < n4) {
+    for (int k = g; k < n_slabs; k += 64) {
+      p0 += slabs[(size_t)k * stride4 + i];
+      if (k + 16 < n_slabs) p1 += slabs[(size_t)(k + 16) * stride4 + i];
+      if (k + 32 < n_slabs) p2 += slabs[(size_t)(k + 32) * stride4 + i];
+      if (k + 48 < n_slabs) p3 += slabs[(size_t)(k + 48) * stride4 + i];
+    }
+  }
+  part[g][o] = (p0 + p1) + (p2 + p3);
+  __syncthreads();
+  if (g == 0 && i < n4) {
+    f32x4 s = part[0][o];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += part[k][o];
+    sum[i] = s;
+  }
+}
+
+void launch_slab_sum4(const float* slabs, int n_slabs, int stride, int n_vals, float* sum, hipStream_t stream) {
+  const int n4 = n_vals / 4;
+  hipLaunchKernelGGL(slab_sum4_kernel, dim3((n4 + 63) / 64), dim3(1024), 0, stream, (const f32x4*)slabs, n_slabs, stride / 4, n4, (f32x4*)sum);
+}
+
 // out[i] = sum over slabs in a fixed order: thread (o, g) adds slabs g, g+4, ... of output o; the 4 partial sums meet in LDS
 // The 64x64 tile lands at (co0, ci0) of the (cout, cin, 3, 3) gradient; db (only for ci0 == 0) at co0.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int slab_floats,

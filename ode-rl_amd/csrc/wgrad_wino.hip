@@ -171,25 +171,6 @@ __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(const WgradPair* _
   else          wgrad_wino_walk<true>(table, n_eval, esplit, slabs, g_quad0, g_quads, a_quad0, a_quads, smem, lane, wave, dbg);
 }
 
-// sum[i] = sum over slabs in a fixed order (the pattern of wgrad_reduce_kernel)
-__global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(const float* __restrict__ slabs, int n_slabs, float* __restrict__ sum) {
-  __shared__ float part[4][64];
-  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-  if (i < kWgradSlabFloats) {
-    for (int k = g; k < n_slabs; k += 16) {
-      p0 += slabs[(size_t)k * kWgradSlabFloats + i];
-      if (k + 4 < n_slabs) p1 += slabs[(size_t)(k + 4) * kWgradSlabFloats + i];
-      if (k + 8 < n_slabs) p2 += slabs[(size_t)(k + 8) * kWgradSlabFloats + i];
-      if (k + 12 < n_slabs) p3 += slabs[(size_t)(k + 12) * kWgradSlabFloats + i];
-    }
-  }
-  part[g][o] = (p0 + p1) + (p2 + p3);
-  __syncthreads();
-  if (g == 0 && i < kWgradSlabFloats) sum[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
-}
-
 // dg = G^T dU G per channel pair (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]); the 64x64 tile lands at (co0, ci0) of the
 // (cout, cin, 3, 3) gradient, db (only for ci0 == 0) at co0
 __global__ __launch_bounds__(256) void wgrad_wino_finish_kernel(const float* __restrict__ sum, float* __restrict__ dw, float* __restrict__ db,
@@ -236,7 +217,7 @@ int launch_wgrad_wino(const WgradPair* table_dev, int n_eval, int batch, int esp
     for (int ci0 = 0; ci0 < cin; ci0 += 64) {
       hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(batch, esplit), dim3(512), kWwLds, stream, table_dev, n_eval, esplit, slabs, co0 / 4,
                          cout / 4, ci0 / 4, cin / 4, dbg);
-      hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((kWgradSlabFloats + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, sum);
+      launch_slab_sum4(slabs, batch * esplit, kWgradSlabFloats, kWgradSlabFloats, sum, stream);
       hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(16), dim3(256), 0, stream, sum, dw, db, cin, co0, ci0);
     }
   ODEHIP_CHECK_HIP(hipGetLastError());

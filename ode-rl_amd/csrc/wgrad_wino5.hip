@@ -9,7 +9,7 @@
 //
 // Same contract as the other batched weight-gradient kernels: one launch per layer and channel tile, workgroup (sample b, split s)
 // walks its share of the evaluations with the whole gradient tile in MFMA accumulators, one slab per workgroup at the end, a
-// fixed-order sum over the slabs (bitwise reproducible, no float atomics), then G^T . G per channel pair.  36 positions x 64 x 64
+// fixed-order sum over the slabs (launch_slab_sum4, wgrad.hip: bitwise reproducible, no float atomics), then G^T . G per channel pair.  36 positions x 64 x 64
 // accumulators do not fit a workgroup, so the channel tile here is 32 x 32 (four launches per 64x64 tile of the caller).
 //
 // Per chunk of 16 tiles (two tile rows): four threads share a (tile, channel quad) -- the activation transform V = B^T d B as in the
@@ -222,25 +222,6 @@ __global__ __launch_bounds__(512, 1) void wgrad32_wino5_kernel(const WgradPair* 
   }
 }
 
-// sum[i] = sum over slabs in a fixed order
-__global__ __launch_bounds__(256) void wgrad_wino5_sum_kernel(const float* __restrict__ slabs, int n_slabs, int slab_stride, float* __restrict__ sum) {
-  __shared__ float part[4][64];
-  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-  if (i < kW5Slab) {
-    for (int k = g; k < n_slabs; k += 16) {
-      p0 += slabs[(size_t)k * slab_stride + i];
-      if (k + 4 < n_slabs) p1 += slabs[(size_t)(k + 4) * slab_stride + i];
-      if (k + 8 < n_slabs) p2 += slabs[(size_t)(k + 8) * slab_stride + i];
-      if (k + 12 < n_slabs) p3 += slabs[(size_t)(k + 12) * slab_stride + i];
-    }
-  }
-  part[g][o] = (p0 + p1) + (p2 + p3);
-  __syncthreads();
-  if (g == 0 && i < kW5Slab) sum[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
-}
-
 // dg = G^T dM G per channel pair; G rows: [1/4 0 0 0 0], -[1 1 1 1 1]/6, -[1 -1 1 -1 1]/6, [1 2 4 8 16]/24, [1 -2 4 -8 16]/24, [0 0 0 0 1]
 __global__ __launch_bounds__(256) void wgrad_wino5_finish_kernel(const float* __restrict__ sum, float* __restrict__ dw, float* __restrict__ db,
                                                                  int cin_total, int co0, int ci0, int write_bias) {
@@ -296,7 +277,7 @@ int launch_wgrad_wino5(const WgradPair* table_dev, int n_eval, int batch, int es
     for (int as = 0; as < 2; ++as) {
       hipLaunchKernelGGL(wgrad32_wino5_kernel, dim3(batch, esplit), dim3(512), kW5Lds, stream, table_dev, n_eval, esplit, slabs, kWgradSlabFloats,
                          g_quad0 + 8 * cs, g_quads, a_quad0 + 8 * as, a_quads);
-      hipLaunchKernelGGL(wgrad_wino5_sum_kernel, dim3((kW5Slab + 63) / 64), dim3(256), 0, stream, slabs, batch * esplit, kWgradSlabFloats, sum);
+      launch_slab_sum4(slabs, batch * esplit, kWgradSlabFloats, kW5Slab, sum, stream);
       hipLaunchKernelGGL(wgrad_wino5_finish_kernel, dim3(4), dim3(256), 0, stream, sum, dw, db, cin_total, co0 + 32 * cs, ci0 + 32 * as,
                          (int)(write_bias && as == 0));
     }

@@ -164,6 +164,33 @@ def pack_conv_weight_winograd(w, transpose_flip=False):
     return out
 
 
+def pack_conv_weights_many(jobs):
+    """jobs: [(weight (cout,cin,k,k), kind, transpose_flip: bool)], kind 0 / False = pack_conv_weight, 1 / True =
+    pack_conv_weight_winograd (3x3), 2 = pack_conv_weight_winograd5 (5x5) -> list of packed tensors, identical to those calls' results
+    but ONE launch per 32 jobs (odehip_pack_conv_weights)."""
+    outs, recs = [], []
+    for w, kind, tf in jobs:
+        kind = int(kind)
+        require_device_tensor(w, "conv weight")
+        w = w.detach().contiguous()
+        if w.dtype != torch.float32:
+            raise ValueError("conv weights must be float32")
+        co, ci, k, _ = w.shape
+        if tf:
+            co, ci = ci, co
+        out = torch.empty(co * ci * (16 if kind == 1 else (36 if kind == 2 else k * k)), dtype=torch.float32, device=w.device)
+        outs.append(out)
+        recs.append((w, out, co, ci, k, kind, 1 if tf else 0))
+    lib = _lib.load()
+    for i in range(0, len(recs), _lib.MAX_PACK_JOBS):
+        chunk = recs[i:i + _lib.MAX_PACK_JOBS]
+        arr = (_lib.PackJob * len(chunk))()
+        for j, (w, out, co, ci, k, kind, tf) in enumerate(chunk):
+            arr[j].w, arr[j].out, arr[j].cout, arr[j].cin, arr[j].ks, arr[j].kind, arr[j].transpose_flip = _ptr(w), _ptr(out), co, ci, k, kind, tf
+        _lib.check(lib.odehip_pack_conv_weights(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream()))
+    return outs
+
+
 def pack_conv_weight_winograd5(w, transpose_flip=False):
     """(Cout,Cin,5,5) fp32 -> Winograd F(2x2,5x5) image U = G g G^T (36 values per channel pair; csrc/conv_wino5.hip)."""
     require_device_tensor(w, "weight")
@@ -333,9 +360,11 @@ class PackedConvStack:
                 raise ValueError("the HIP path supports stride-1 'same' square convs with bias only "
                                  f"(got {c}); downsize=True dynamics are not supported")
             require_device_tensor(c.weight, "conv weight")
-        packed = [pack_conv_weight(c.weight) for c in convs]
         wino_ok = USE_WINOGRAD and ks == 3
-        wino = [pack_conv_weight_winograd(c.weight) if wino_ok and c.in_channels % 16 == 0 else None for c in convs]
+        want_wino = [wino_ok and c.in_channels % 16 == 0 for c in convs]
+        both = pack_conv_weights_many([(c.weight, False, False) for c in convs] + [(c.weight, True, False) for c, ww in zip(convs, want_wino) if ww])
+        packed, rest = both[:len(convs)], iter(both[len(convs):])
+        wino = [next(rest) if ww else None for ww in want_wino]
         bf16 = [pack_conv_weight_bf16(c.weight) if mode == "bf16" and _bf16_ok(c.in_channels, c.out_channels, ks) else None
                 for c in convs]
         bias = [c.bias.detach().contiguous() for c in convs]
@@ -362,9 +391,11 @@ class PackedConvStack:
         d0 = self.refresh(mode)
         ent = self._cache[mode]
         if ent["dgrad"] is None:
-            packed = [pack_conv_weight(c.weight, transpose_flip=True) for c in self.convs]
-            wino = [pack_conv_weight_winograd(c.weight, transpose_flip=True)
-                    if USE_WINOGRAD and d0.ks == 3 and c.out_channels % 16 == 0 else None for c in self.convs]
+            want_wino = [USE_WINOGRAD and d0.ks == 3 and c.out_channels % 16 == 0 for c in self.convs]
+            both = pack_conv_weights_many([(c.weight, False, True) for c in self.convs] +
+                                          [(c.weight, True, True) for c, ww in zip(self.convs, want_wino) if ww])
+            packed, rest = both[:len(self.convs)], iter(both[len(self.convs):])
+            wino = [next(rest) if ww else None for ww in want_wino]
             bf16 = [pack_conv_weight_bf16(c.weight, transpose_flip=True)
                     if mode == "bf16" and _bf16_ok(c.out_channels, c.in_channels, d0.ks) else None for c in self.convs]
             fused = pack_fused_bf16(self.convs, reverse_transposed=True) if mode == "bf16" and _fusable(self.convs, d0.ks) else None
@@ -816,14 +847,14 @@ class PackedCell:
             raise ValueError("the HIP ConvGRU supports 'same' padding only")
         if c.conv_gates[1].num_groups * 32 != 2 * c.hidden_dim or c.conv_can[1].num_groups * 32 != c.hidden_dim:
             raise ValueError("the HIP ConvGRU needs GroupNorm groups of 32 channels (hidden_dim multiple of 32)")
-        keep = [pack_conv_weight(ps[0]), ps[1].detach().contiguous(), ps[2].detach().contiguous(), ps[3].detach().contiguous(),
-                pack_conv_weight(ps[4]), ps[5].detach().contiguous(), ps[6].detach().contiguous(), ps[7].detach().contiguous()]
+        want_wino = mode == "f32" and ks == 5 and winograd5_enabled() and c.input_channels % 8 == 0 and c.hidden_dim % 32 == 0
+        packs = pack_conv_weights_many([(ps[0], 0, False), (ps[4], 0, False)] + ([(ps[0], 2, False), (ps[4], 2, False)] if want_wino else []))
+        keep = [packs[0], ps[1].detach().contiguous(), ps[2].detach().contiguous(), ps[3].detach().contiguous(),
+                packs[1], ps[5].detach().contiguous(), ps[6].detach().contiguous(), ps[7].detach().contiguous()]
         bf = [None, None]
         if mode == "bf16" and _bf16_cell_ok(c.input_channels, c.hidden_dim, ks):
             bf = [pack_conv_weight_bf16_ks(ps[0]), pack_conv_weight_bf16_ks(ps[4])]
-        wino = [None, None]
-        if mode == "f32" and ks == 5 and winograd5_enabled() and c.input_channels % 8 == 0 and c.hidden_dim % 32 == 0:
-            wino = [pack_conv_weight_winograd5(ps[0]), pack_conv_weight_winograd5(ps[4])]
+        wino = packs[2:4] if want_wino else [None, None]
         keep = keep + wino
         d = _lib.ConvGRUCellDesc(input=c.input_channels, hidden=c.hidden_dim, ks=ks,
                                  w_gates_wino=wino[0].data_ptr() if wino[0] is not None else None,
@@ -838,19 +869,21 @@ class PackedCell:
         return d
 
 
-def _cell_bwd_packs(cell, d, mode):
-    """Transposed + flipped slices of the two 5x5 weights (frame half, state half), fp32 images and, in bf16 mode, bf16 ones."""
+def _cell_bwd_packs(cell, d, mode, extra_jobs=()):
+    """Transposed + flipped slices of the two 5x5 weights (frame half, state half), fp32 images and, in bf16 mode, bf16 ones; extra_jobs
+    (pack_conv_weights_many tuples) ride in the same launch and their results follow the four slices in the first list."""
     i = d.input
     wg, wc = cell.conv_gates[0].weight.detach(), cell.conv_can[0].weight.detach()
     slices = [wg[:, :i], wg[:, i:], wc[:, :i], wc[:, i:]]
-    keep = [pack_conv_weight(w, True) for w in slices]
+    slices = [w.contiguous() for w in slices]
+    want_wino = mode == "f32" and d.ks == 5 and winograd5_enabled() and all(w.shape[0] % 8 == 0 and w.shape[1] % 32 == 0 for w in slices)
+    packs = pack_conv_weights_many([(w, 0, True) for w in slices] + list(extra_jobs) + ([(w, 2, True) for w in slices] if want_wino else []))
+    keep, extra = packs[:4], packs[4:4 + len(extra_jobs)]
     bf = [None] * 4
     if mode == "bf16" and d.ks == 5 and all(w.shape[0] <= 128 and w.shape[0] % 16 == 0 and w.shape[1] % 32 == 0 for w in slices):
         bf = [pack_conv_weight_bf16_ks(w, True) for w in slices]
-    wino = [None] * 4
-    if mode == "f32" and d.ks == 5 and winograd5_enabled() and all(w.shape[0] % 8 == 0 and w.shape[1] % 32 == 0 for w in slices):
-        wino = [pack_conv_weight_winograd5(w, True) for w in slices]
-    return keep, bf, wino
+    wino = packs[4 + len(extra_jobs):] if want_wino else [None] * 4
+    return keep + extra, bf, wino
 
 
 def convgru_cell_forward(packed_cell, x, h):
@@ -914,8 +947,8 @@ class PackedEncoder:
         stamp = (id(fd), id(cd)) + tuple((p.data_ptr(), p._version) for p in ps)
         if stamp == self._stamp:
             return self.desc
-        keep = [pack_conv_weight(h0.weight), h0.bias.detach().contiguous(), pack_conv_weight(h1.weight),
-                h1.bias.detach().contiguous()]
+        hw = pack_conv_weights_many([(h0.weight, 0, False), (h1.weight, 0, False)])
+        keep = [hw[0], h0.bias.detach().contiguous(), hw[1], h1.bias.detach().contiguous()]
         d = _lib.EncoderDesc()
         d.f_enc = fd
         d.cell = cd
@@ -945,8 +978,8 @@ def _encoder_bwd_desc(enc):
     cached = getattr(enc, "_bwd", None)
     if cached is not None and cached[0] is stamp:
         return cached[1]
-    keep, bf, wino = _cell_bwd_packs(enc.packed_cell.cell, d.cell, current_compute_dtype())
-    keep += [pack_conv_weight(enc.head[0].weight, True), pack_conv_weight(enc.head[2].weight, True)]
+    keep, bf, wino = _cell_bwd_packs(enc.packed_cell.cell, d.cell, current_compute_dtype(),
+                                     extra_jobs=[(enc.head[0].weight, 0, True), (enc.head[2].weight, 0, True)])
     b = _lib.EncoderBwd()
     b.f_dgrad = enc.f_stack.dgrad_desc()
     b.w_gates_dx, b.w_gates_dh, b.w_can_dx, b.w_can_dh, b.w_head0_t, b.w_head1_t = (k.data_ptr() for k in keep)
@@ -1138,9 +1171,10 @@ def frame_encode(seq, frames):
     return out
 
 
-def frame_decode(seq, latents, apply_sigmoid):
+def frame_decode(seq, latents, apply_sigmoid, save_mid=False):
     """`seq` = the reference Decoder's nn.Sequential (n_ups = 2).  latents (..., C, 16, 16) (any leading dims, e.g. the solver's
-    (T,B)) -> (..., out_ch, 64, 64); apply_sigmoid folds the F.sigmoid of ODEConvGRU.py:85 into the launch."""
+    (T,B)) -> (..., out_ch, 64, 64); apply_sigmoid folds the F.sigmoid of ODEConvGRU.py:85 into the launch.  save_mid: also return
+    the 32-channel intermediate (N, 32 x 32 x 32 floats, the layout of odehip_frame_decode_train) for the backward pass."""
     require_device_tensor(latents, "latents")
     if not frame_decoder_supported(seq):
         raise ValueError("frame_decode: not the reference's Decoder structure (ConvTranspose2d 4/2/1 -> LeakyReLU -> ConvTranspose2d 4/2/1)")
@@ -1156,9 +1190,10 @@ def frame_decode(seq, latents, apply_sigmoid):
     pack = _codec_pack(seq, c1, c2, lib.odehip_frame_decoder_pack_floats(c1.in_channels, c2.out_channels), lib.odehip_pack_frame_decoder,
                        c1.in_channels, c2.out_channels)
     out = torch.empty(lead + (c2.out_channels, 64, 64), dtype=torch.float32, device=latents.device)
-    _lib.check(lib.odehip_frame_decode(_ptr(pack), _ptr(latents), n, c1.in_channels, c2.out_channels, slope, 1 if apply_sigmoid else 0,
-                                       _ptr(out), _stream()))
-    return out
+    mid = torch.empty((n, 32 * 32 * 32), dtype=torch.float32, device=latents.device) if save_mid else None
+    _lib.check(lib.odehip_frame_decode_train(_ptr(pack), _ptr(latents), n, c1.in_channels, c2.out_channels, slope, 1 if apply_sigmoid else 0,
+                                             _ptr(out), _ptr(mid) if save_mid else None, _stream()))
+    return (out, mid) if save_mid else out
 
 
 
@@ -1218,14 +1253,20 @@ class _FrameDecodeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, seq, latents, apply_sigmoid, w1, b1, w2, b2):
-        pred = frame_decode(seq, latents, apply_sigmoid)
-        ctx.seq, ctx.apply_sigmoid = seq, bool(apply_sigmoid)
-        ctx.save_for_backward(latents, pred, w1)
+        # ODEHIP_CODEC_SAVE_MID=0: keep nothing but inputs and outputs, the backward recomputes the intermediate (32 KiB per image less
+        # memory, ~0.1 ms more per 640 images)
+        if os.environ.get("ODEHIP_CODEC_SAVE_MID", "1") != "0":
+            pred, mid = frame_decode(seq, latents, apply_sigmoid, save_mid=True)
+        else:
+            pred, mid = frame_decode(seq, latents, apply_sigmoid), None
+        ctx.seq, ctx.apply_sigmoid, ctx.has_mid = seq, bool(apply_sigmoid), mid is not None
+        ctx.save_for_backward(latents, pred, w1, *([mid] if mid is not None else []))
         return pred
 
     @staticmethod
     def backward(ctx, g):
-        latents, pred, w1 = ctx.saved_tensors
+        latents, pred, w1 = ctx.saved_tensors[:3]
+        mid = ctx.saved_tensors[3] if ctx.has_mid else None
         seq = ctx.seq
         c1, c2, slope = _codec_layers(seq, torch.nn.ConvTranspose2d, 4, 32)
         lib = _lib.load()
@@ -1238,7 +1279,8 @@ class _FrameDecodeFn(torch.autograd.Function):
         dw2, db2 = torch.empty_like(c2.weight), torch.empty_like(c2.bias)
         nws = int(lib.odehip_frame_decode_backward_workspace_floats(n, c1.in_channels, 1))
         ws = torch.empty(nws, dtype=torch.float32, device=lat.device)
-        _lib.check(lib.odehip_frame_decode_backward(_ptr(pack), _ptr(w1.detach().contiguous()), _ptr(lat), _ptr(pred), _ptr(g), n, c1.in_channels, 1,
+        _lib.check(lib.odehip_frame_decode_backward(_ptr(pack), _ptr(w1.detach().contiguous()), _ptr(lat), _ptr(mid) if mid is not None else None,
+                                                    _ptr(pred), _ptr(g), n, c1.in_channels, 1,
                                                     slope, 1 if ctx.apply_sigmoid else 0, _ptr(g_lat), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
                                                     _ptr(ws), nws, _stream()))
         return None, g_lat.view_as(latents), None, dw1, db1, dw2, db2

@@ -19,7 +19,7 @@ def train_batch(model, batch_dict, optimizer, async_solver=True):
     from . import hip_ops
     was = hip_ops.set_async_dopri5(True) if async_solver else hip_ops._async_dopri5
     try:
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad()   # torch 2 default (set_to_none=True), as train_test.py:176 today: no fill + accumulate kernels per parameter
         pred = model.get_prediction(inp, batch_dict=batch_dict)
         loss = model.get_loss(pred, out)
         loss.backward()

@@ -138,3 +138,26 @@ def test_winograd5_conv_matches_torch(cuda, b, cin1, cin2, cout, relu):
     dg = hip_ops.q4_to_nchw(hip_ops.conv_q4(hip_ops.nchw_to_q4(gy.to(cuda)), hip_ops.pack_conv_weight(wd, transpose_flip=True), None,
                                             cin, 5, w_wino=hip_ops.pack_conv_weight_winograd5(wd, transpose_flip=True)))
     assert rel_l2(dg, xr.grad) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_pack_many_equals_the_single_packs(cuda):
+    """odehip_pack_conv_weights (one launch for a whole conv stack) writes exactly what the per-tensor pack calls write"""
+    from ode_rl_amd import hip_ops
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(64, 64, 3, 3, generator=g), torch.randn(128, 64, 3, 3, generator=g), torch.randn(64, 128, 3, 3, generator=g),
+          torch.randn(32, 64, 5, 5, generator=g), torch.randn(64, 32, 1, 1, generator=g)]
+    ws = [w.to(cuda) for w in ws]
+    jobs = []
+    for w in ws:
+        for tf in (False, True):
+            jobs.append((w, 0, tf))
+            if w.shape[-1] == 3:
+                jobs.append((w, 1, tf))
+            if w.shape[-1] == 5:
+                jobs.append((w, 2, tf))
+    jobs = jobs * 3   # 48 jobs: more than one launch of ODEHIP_MAX_PACK_JOBS
+    got = hip_ops.pack_conv_weights_many(jobs)
+    single = (hip_ops.pack_conv_weight, hip_ops.pack_conv_weight_winograd, hip_ops.pack_conv_weight_winograd5)
+    for (w, kind, tf), out in zip(jobs, got):
+        assert torch.equal(out, single[kind](w, transpose_flip=tf)), (tuple(w.shape), kind, tf)

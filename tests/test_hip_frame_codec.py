@@ -121,8 +121,8 @@ def test_model_takes_the_fused_launches_with_and_without_autograd(cuda, monkeypa
     model = model.to(cuda)
     calls = []
     real_e, real_d = hip_ops.frame_encode, hip_ops.frame_decode
-    monkeypatch.setattr(hip_ops, "frame_encode", lambda *a: (calls.append("enc"), real_e(*a))[1])
-    monkeypatch.setattr(hip_ops, "frame_decode", lambda *a: (calls.append("dec"), real_d(*a))[1])
+    monkeypatch.setattr(hip_ops, "frame_encode", lambda *a, **k: (calls.append("enc"), real_e(*a, **k))[1])
+    monkeypatch.setattr(hip_ops, "frame_decode", lambda *a, **k: (calls.append("dec"), real_d(*a, **k))[1])
     frames = procedural_tensor((2, 4, 1, 64, 64), 130, 0, 1).to(cuda)
     truth = procedural_tensor((2, 4, 1, 64, 64), 133, 0, 1).to(cuda)
     ts = torch.tensor(np.arange(8) / 8).to(cuda)
@@ -255,6 +255,28 @@ def test_backward_is_bitwise_reproducible_and_handles_kinks(cuda):
     want = [want_e[k] for k, _ in enc.named_parameters()] + [want_d[k] for k, _ in dec.named_parameters()] + [want_z]
     for got, w in zip(a, want):
         assert rel_l2(got, w.float()) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lat", [64, 32])
+def test_decoder_backward_with_saved_and_with_recomputed_intermediate_agree_bitwise(cuda, lat, monkeypatch):
+    """the training forward saves the 32-channel intermediate (odehip_frame_decode_train); ODEHIP_CODEC_SAVE_MID=0 recomputes it in the
+    backward kernel from the latents: the same arithmetic, so the same bits in every gradient"""
+    from ode_rl_amd import hip_ops
+    dec = _decoder(lat, 1, 72).to(cuda)
+    z = procedural_tensor((3, 5, lat, 16, 16), 172, -2, 2).to(cuda)
+    g = procedural_tensor((3, 5, 1, 64, 64), 174, -1, 1).to(cuda)
+
+    def run():
+        dec.zero_grad()
+        zc = z.clone().requires_grad_(True)
+        pred = hip_ops.frame_decode_autograd(dec.decoder, zc, True)
+        pred.backward(g)
+        return [pred.detach().clone(), zc.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+    saved = run()
+    monkeypatch.setenv("ODEHIP_CODEC_SAVE_MID", "0")
+    recomputed = run()
+    assert all(torch.equal(u, v) for u, v in zip(saved, recomputed))
 
 
 @pytest.mark.gpu

@@ -58,7 +58,7 @@ def main():
             return m(frames, bd)
 
     def train():
-        optim.zero_grad(set_to_none=False)
+        optim.zero_grad()   # torch 2 default (set_to_none=True): what the reference's `optimizer.zero_grad()` (train_test.py:176) does today
         loss = m.get_loss(m(frames, bd), truth)
         loss.backward()
         optim.step()
