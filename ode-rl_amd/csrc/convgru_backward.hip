@@ -296,7 +296,7 @@ struct EncLayout {
     off_pgg = take((size_t)2 * T * B * 2 * C * 4);
     off_pgc = take((size_t)2 * T * B * C * 4);
     off_tab = take((size_t)T * sizeof(WgradPair));
-    off_slab = take(((size_t)B * 4 + 1) * kWgradSlabFloats * 4);
+    off_slab = take(((size_t)B * wgrad_esplit_max(B) + 1) * kWgradSlabFloats * 4);
     total = o;
   }
   float* p(void* ws, size_t off) const { return (float*)((char*)ws + off); }
@@ -527,7 +527,9 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
       host[idx].pad_[0] = host[idx].pad_[1] = host[idx].pad_[2] = 0.0f;
     }
     if ((rc = put_table(T)) != ODEHIP_OK) return rc;
-    rc = launch_wgrad(table, T, batch, 4, slabs, gr->f_w[l], gr->f_b[l], e->f_enc.channels[l + 1], e->f_enc.channels[l], stream, (&e->f_enc)->w_bf16[l] != nullptr);
+    // (fp32: 256 / batch workgroups per sample share the frames -- a batch of 4 with esplit 4 kept 240 CUs idle)
+    rc = launch_wgrad(table, T, batch, (&e->f_enc)->w_bf16[l] ? 4 : wgrad_esplit(batch, T), slabs, gr->f_w[l], gr->f_b[l], e->f_enc.channels[l + 1],
+                      e->f_enc.channels[l], stream, (&e->f_enc)->w_bf16[l] != nullptr);
     if (rc != ODEHIP_OK) return rc;
   }
   // ConvGRU convs on cat(x, state): the two halves of the input are separate tensors
@@ -551,7 +553,7 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
             rc = launch_wgrad_tile_bf16_5x5(table, T, batch, 4, slabs, J.dw, J.db, 2 * C, co0, half * C + ci0, J.g_ch / 4, co0 / 4, C / 4,
                                             ci0 / 4, half == 0 && ci0 == 0, stream);
           else
-            rc = launch_wgrad_tile(table, T, batch, 4, slabs, J.dw, J.db, ks, 2 * C, co0, half * C + ci0, J.g_ch / 4, co0 / 4, C / 4,
+            rc = launch_wgrad_tile(table, T, batch, wgrad_esplit(batch, T), slabs, J.dw, J.db, ks, 2 * C, co0, half * C + ci0, J.g_ch / 4, co0 / 4, C / 4,
                                    ci0 / 4, half == 0 && ci0 == 0, stream);
           if (rc != ODEHIP_OK) return rc;
         }
@@ -604,7 +606,7 @@ struct CellBwdLayout {
     g_cand = take(hs); g_gates = take(2 * hs); gz_pre = take(hs); gh_ode = take(hs); g_rh = take(hs); gh = take(hs);
     pg = take((size_t)6 * batch * c->hidden * 4);  // [dgamma_g | dbeta_g] (2H each) then [dgamma_c | dbeta_c] (H each), per sample
     table = take(sizeof(WgradPair));
-    slabs = take(((size_t)batch * 4 + 1) * kWgradSlabFloats * 4);
+    slabs = take(((size_t)batch * wgrad_esplit_max(batch) + 1) * kWgradSlabFloats * 4);
     total = o;
   }
 };

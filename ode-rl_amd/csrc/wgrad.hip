@@ -366,13 +366,17 @@ static int launch_tile_part(const WgradPair* table_dev, int n_eval, int batch, i
 
 // One 64 x 64 tile of dW (cout_total, cin_total, ks, ks): output channels co0.. from G tensors with g_quads quads per sample
 // (tile at quad g_quad0), input channels ci0.. of the WEIGHT from A tensors with a_quads quads per sample (tile at a_quad0) --
-// the A tensor may be one half of a concatenated conv input.  slabs: batch*esplit*(64*64*10+64) floats.
+// the A tensor may be one half of a concatenated conv input.  slabs: batch*esplit*(64*64*10+64) floats (ks == 5:
+// (batch * wgrad_esplit_max(batch) + 1) * kWgradSlabFloats).
 int launch_wgrad_tile(const WgradPair* table_dev, int n_eval, int batch, int esplit, float* slabs, float* dw, float* db, int ks,
                       int cin_total, int co0, int ci0, int g_quads, int g_quad0, int a_quads, int a_quad0, bool write_bias,
                       hipStream_t stream) {
   int rc;
   if (ks == 5) {   // fp32 5x5: the Winograd-domain kernel (36 instead of 100 multiplies per 2x2 outputs, wgrad_wino5.hip) unless switched off
-    rc = launch_wgrad_wino5(table_dev, n_eval, batch, esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads, a_quad0, write_bias,
+    // its work units are (evaluation, chunk of 16 tiles) pairs: up to 4 n_eval splits are useful (small batches; the 5x5 callers' slab
+    // areas hold batch * wgrad_esplit_max(batch) + 1 slabs)
+    const int e5 = wgrad_esplit(batch, 4 * n_eval);
+    rc = launch_wgrad_wino5(table_dev, n_eval, batch, e5 > esplit ? e5 : esplit, slabs, dw, db, cin_total, co0, ci0, g_quads, g_quad0, a_quads, a_quad0, write_bias,
                             stream);
     if (rc != 1) return rc;
   }
