@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "odehip_internal.h"
+#include "persist.h"
 
 namespace odehip {
 
@@ -295,7 +296,7 @@ struct EncLayout {
     off_gheadhid = take(hh);
     off_pgg = take((size_t)2 * T * B * 2 * C * 4);
     off_pgc = take((size_t)2 * T * B * C * 4);
-    off_tab = take((size_t)T * sizeof(WgradPair));
+    off_tab = take((size_t)(ODEHIP_MAX_LAYERS + 6) * T * sizeof(WgradPair));  // every weight-gradient table of a backward pass: ONE upload
     off_slab = take(((size_t)B * wgrad_esplit_max(B) + 1) * kWgradSlabFloats * 4);
     total = o;
   }
@@ -515,38 +516,53 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
   if (rc != ODEHIP_OK) return rc;
 
   // ---- weight gradients: one launch per (layer, 64x64 tile) over all frames
-  WgradPair* table = (WgradPair*)L.p(ws, L.off_tab);
+  // All tables (NL dynamics layers, 2 x 2 ConvGRU halves, 2 head layers; T entries each) are built first and go up in ONE
+  // asynchronous copy (a fill launch per 256 bytes before: 21 launches of 5 us per backward pass).
+  WgradPair* const table0 = (WgradPair*)L.p(ws, L.off_tab);
   float* slabs = L.p(ws, L.off_slab);
-  std::vector<WgradPair> host(T);
-  auto put_table = [&](int n) { return upload_bytes(table, host.data(), (size_t)n * sizeof(WgradPair), stream); };
-  for (int l = 0; l < NL; ++l) {  // encoder dynamics (3x3), weight of frame idx = its Euler dt
-    for (int idx = 0; idx < T; ++idx) {
-      host[idx].g = L.gp(ws, idx, l);
-      host[idx].a = l == 0 ? L.hstate(ws, idx) : L.hidden(ws, idx, l - 1);
-      host[idx].scale = frame_dt(t_host, T, idx, run_backwards);
-      host[idx].pad_[0] = host[idx].pad_[1] = host[idx].pad_[2] = 0.0f;
-    }
-    if ((rc = put_table(T)) != ODEHIP_OK) return rc;
-    // (fp32: 256 / batch workgroups per sample share the frames -- a batch of 4 with esplit 4 kept 240 CUs idle)
-    rc = launch_wgrad(table, T, batch, (&e->f_enc)->w_bf16[l] ? 4 : wgrad_esplit(batch, T), slabs, gr->f_w[l], gr->f_b[l], e->f_enc.channels[l + 1],
-                      e->f_enc.channels[l], stream, (&e->f_enc)->w_bf16[l] != nullptr);
-    if (rc != ODEHIP_OK) return rc;
-  }
-  // ConvGRU convs on cat(x, state): the two halves of the input are separate tensors
+  std::vector<WgradPair> host((size_t)(NL + 6) * T);
+  memset(host.data(), 0, host.size() * sizeof(WgradPair));
   struct CatJob {
     size_t g_off; int g_ch; size_t a2_off; float* dw; float* db;
   } jobs[2] = {{L.off_ggates, 2 * C, L.off_hode, gr->w_gates, gr->b_gates}, {L.off_gcand, C, L.off_rh, gr->w_can, gr->b_can}};
+  for (int l = 0; l < NL; ++l)   // encoder dynamics (3x3), weight of frame idx = its Euler dt
+    for (int idx = 0; idx < T; ++idx) {
+      WgradPair& h = host[(size_t)l * T + idx];
+      h.g = L.gp(ws, idx, l);
+      h.a = l == 0 ? L.hstate(ws, idx) : L.hidden(ws, idx, l - 1);
+      h.scale = frame_dt(t_host, T, idx, run_backwards);
+    }
+  for (int j = 0; j < 2; ++j) {   // ConvGRU convs on cat(x, state): the two halves of the input are separate tensors
+    const size_t gbytes = (size_t)(jobs[j].g_ch / C) * L.hs;
+    for (int half = 0; half < 2; ++half)
+      for (int idx = 0; idx < T; ++idx) {
+        WgradPair& h = host[(size_t)(NL + 2 * j + half) * T + idx];
+        h.g = L.per(ws, jobs[j].g_off, idx, gbytes);
+        h.a = half == 0 ? L.frame(ws, visited_frame(T, idx, run_backwards)) : L.per(ws, jobs[j].a2_off, idx, L.hs);
+        h.scale = 1.0f;
+      }
+  }
+  {   // head 1x1 convs (one entry each)
+    WgradPair& h1 = host[(size_t)(NL + 4) * T];
+    h1.g = L.p(ws, L.off_gheadout);
+    h1.a = L.p(ws, L.off_headhid);
+    h1.scale = 1.0f;
+    WgradPair& h0 = host[(size_t)(NL + 5) * T];
+    h0.g = L.p(ws, L.off_gheadhid);
+    h0.a = L.hstate(ws, T);
+    h0.scale = 1.0f;
+  }
+  if ((rc = staged_upload(table0, host.data(), host.size() * sizeof(WgradPair), stream)) != ODEHIP_OK) return rc;
+  for (int l = 0; l < NL; ++l) {
+    // (fp32: 256 / batch workgroups per sample share the frames -- a batch of 4 with esplit 4 kept 240 CUs idle)
+    rc = launch_wgrad(table0 + (size_t)l * T, T, batch, (&e->f_enc)->w_bf16[l] ? 4 : wgrad_esplit(batch, T), slabs, gr->f_w[l], gr->f_b[l],
+                      e->f_enc.channels[l + 1], e->f_enc.channels[l], stream, (&e->f_enc)->w_bf16[l] != nullptr);
+    if (rc != ODEHIP_OK) return rc;
+  }
   for (int j = 0; j < 2; ++j) {
     const CatJob& J = jobs[j];
-    const size_t gbytes = (size_t)(J.g_ch / C) * L.hs;
     for (int half = 0; half < 2; ++half) {
-      for (int idx = 0; idx < T; ++idx) {
-        host[idx].g = L.per(ws, J.g_off, idx, gbytes);
-        host[idx].a = half == 0 ? L.frame(ws, visited_frame(T, idx, run_backwards)) : L.per(ws, J.a2_off, idx, L.hs);
-        host[idx].scale = 1.0f;
-        host[idx].pad_[0] = host[idx].pad_[1] = host[idx].pad_[2] = 0.0f;
-      }
-      if ((rc = put_table(T)) != ODEHIP_OK) return rc;
+      const WgradPair* const table = table0 + (size_t)(NL + 2 * j + half) * T;
       for (int co0 = 0; co0 < J.g_ch; co0 += 64)
         for (int ci0 = 0; ci0 < C; ci0 += 64) {
           if (ks == 5 && e->cell.w_gates_bf16)  // bf16 compute mode: operands rounded to bf16, fp32 accumulation
@@ -559,22 +575,15 @@ extern "C" int odehip_odeconvgru_encode_backward(const odehip_encoder* e, const 
         }
     }
   }
-  // head 1x1 convs
   {
-    host[0].scale = 1.0f;
-    host[0].pad_[0] = host[0].pad_[1] = host[0].pad_[2] = 0.0f;
-    host[0].g = L.p(ws, L.off_gheadout);
-    host[0].a = L.p(ws, L.off_headhid);
-    if ((rc = put_table(1)) != ODEHIP_OK) return rc;
+    const WgradPair* table = table0 + (size_t)(NL + 4) * T;
     for (int co0 = 0; co0 < OUT2; co0 += 64)
       for (int ci0 = 0; ci0 < HH; ci0 += 64) {
         rc = launch_wgrad_tile(table, 1, batch, 4, slabs, gr->w_head1, gr->b_head1, 1, HH, co0, ci0, OUT2 / 4, co0 / 4, HH / 4, ci0 / 4,
                                ci0 == 0, stream);
         if (rc != ODEHIP_OK) return rc;
       }
-    host[0].g = L.p(ws, L.off_gheadhid);
-    host[0].a = L.hstate(ws, T);
-    if ((rc = put_table(1)) != ODEHIP_OK) return rc;
+    table = table0 + (size_t)(NL + 5) * T;
     for (int co0 = 0; co0 < HH; co0 += 64)
       for (int ci0 = 0; ci0 < C; ci0 += 64) {
         rc = launch_wgrad_tile(table, 1, batch, 4, slabs, gr->w_head0, gr->b_head0, 1, C, co0, ci0, HH / 4, co0 / 4, C / 4, ci0 / 4,
