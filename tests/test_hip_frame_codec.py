@@ -114,6 +114,7 @@ def test_model_takes_the_fused_launches_with_and_without_autograd(cuda, monkeypa
     import argparse
     from ode_rl_amd import hip_ops
     from ode_rl_amd.models.ODEConvGRU import ODEConvGRU
+    monkeypatch.delenv("ODEHIP_CODEC_BACKWARD", raising=False)   # this test sets the switch itself (the suite may run with it off)
     opt = argparse.Namespace(resolution=64, n_downs=2, conv_encoder_out_ch=64, in_channels=1, n_ode_layers=3, neural_ode_n_units=64,
                              neural_ode_decoder_out_ch=64, decode_diff_method="rk4", mem=False, z_sample=False)
     model = ODEConvGRU(opt, torch.device("cpu"))
