@@ -5,10 +5,12 @@
 //   Decoder  ConvTranspose2d(C, 32, 4, 2, 1) -> LeakyReLU -> ConvTranspose2d(32, 1, 4, 2, 1) -> sigmoid     d latents, dW1 db1 dW2 db2
 //
 // for C = 32 or 64 latent channels and one frame channel.  Under autograd these were eight library launches plus layout
-// transposes and elementwise kernels (1.2 ms + ~0.5 ms of a 13.5 ms training step at B = 64, 10 + 10 frames); here:
+// transposes and elementwise kernels (1.2 ms + ~0.5 ms of a 13.5 ms training step at B = 64, 10 + 10 frames); here (0.43 ms):
 //
-//   frame_decode_bwd_mid_kernel   per (image, quarter): the 32-channel intermediate is RECOMPUTED in LDS (dec_mid_to_lds, the forward's
-//                                 own routine), g = dL/d(pre-sigmoid) staged as an [18][66] tile; each thread owns one intermediate
+//   frame_decode_bwd_mid_kernel   per (image, quarter): the 32-channel intermediate as an LDS tile -- read back from the copy the training
+//                                 forward saved (odehip_frame_decode_train; 161 -> 49 us per 640 images), or RECOMPUTED from the latents
+//                                 by the forward's own routine (dec_mid_to_lds) when nothing but inputs and outputs is to be kept --,
+//                                 g = dL/d(pre-sigmoid) staged as an [18][66] tile; each thread owns one intermediate
 //                                 pixel: its gradient through the 4x4 window of g (VALU, weights as scalar loads), LeakyReLU mask,
 //                                 written once to HBM as channel quads; dW2 as an MFMA product (k = pixels; a third block with A = 1
 //                                 yields db2).
