@@ -1210,7 +1210,9 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
   if (e_combine == 1) {
     const CombineArgs& m = a.cmb;
     e_np = m.n_prev;
-    e_h = m.atol;   // the step size by value (persistent tables of the fixed-grid drivers)
+    // the step size by value (persistent tables of the fixed-grid drivers), or through its pointer (a single evaluation whose dt
+    // only exists on the device: the encoder loop's Euler step)
+    e_h = a.h_by_value ? m.atol : (m.h_ptr ? *(ConstF16*)m.h_ptr : 1.0f);
     e_ks = m.k_scale;
     e_c1c = m.c1[e_np];
     e_c2c = m.c2[e_np];

@@ -37,6 +37,9 @@ struct PersistState {
   } vol[kVolSlots];
   int vol_next = 0;
   int vol_last = -1;   // slot of the upload that has not been followed by its launch yet
+  // single evaluations on the trajectory walks (ODEHIP_EVAL_WALK=1): a flag area of the library, zeroed in front of every launch
+  unsigned* eval_sync = nullptr;
+  int eval_batch_cap = 0;
   // small launches: flag area that is never zeroed between launches (words are tagged with the launch's epoch)
   unsigned* small_flags = nullptr;
   int small_batch_cap = 0;
@@ -252,6 +255,19 @@ PersistScope::~PersistScope() {
 int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, int max_layers, bool small) {
     small_ = small;
     if (small && (g_conv_recorder || max_layers > 5)) return ODEHIP_OK;  // inside an outer scope: its recorder takes the layers
+    // ODEHIP_EVAL_WALK=1: the <= 5 layers of a single evaluation / input-gradient chain (the encoder loop's Euler step and its
+    // backward) as ONE launch of the TRAJECTORY walks -- wino_persist_kernel, or the sixteen-workgroup walk up to batch 16 -- instead
+    // of the round-2 single-evaluation kernel below (9.5 us per layer against 7.5 / 3.3): the table goes up through the volatile
+    // ring, the flags live in a library-owned area zeroed per launch.  Like the small launches: no NaN guard, errors are reported late.
+    static const bool eval_walk_on = [] { const char* e = getenv("ODEHIP_EVAL_WALK"); return e && e[0] == '1'; }();
+    if (small && eval_walk_on) {
+      small_ = false;
+      eval_walk_ = true;
+      volatile_ = true;
+      small = false;
+      for (int l = 0; l <= f->n_convs; ++l)
+        if (f->channels[l] != 64) return ODEHIP_OK;   // 64-channel stacks only here
+    }
     if (small) {
       // Measured (dopri5 forward + backward, B=64): 55 us per 5-layer launch = 11 us per layer, no better than five launches --
       // the last layer of an adaptive solver's evaluation combines up to six earlier stages through the shared epilogue
@@ -294,7 +310,21 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;
     if (!active_) return ODEHIP_OK;
     active_ = false;
-    bool all_ok = rec_.count > 0, wide = false, adaptive = adaptive_;
+    if (eval_walk_ && !sync) {   // the library's flag area (grown synchronously, rarely)
+      PersistState& P = g_persist;
+      if (batch > P.eval_batch_cap) {
+        bool ok = hipStreamSynchronize(stream) == hipSuccess;
+        if (ok && P.eval_sync) (void)hipFree(P.eval_sync);
+        P.eval_sync = nullptr;
+        P.eval_batch_cap = 0;
+        const int cap = batch < 64 ? 64 : batch;
+        ok = ok && hipMalloc((void**)&P.eval_sync, persist_sync_bytes(cap)) == hipSuccess;
+        if (ok) P.eval_batch_cap = cap;
+      }
+      sync = P.eval_sync;   // null: the recorded layers are replayed below
+      sync_is_zero = false;
+    }
+    bool all_ok = rec_.count > 0 && !(eval_walk_ && !sync), wide = false, adaptive = adaptive_;
     for (int i = 0; i < rec_.count && all_ok; ++i) {
       const int kind = persist_layer_kind(rec_.items[i]);
       all_ok = kind != 0;
@@ -370,7 +400,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
         if (a.combine >= 4) continue;   // elementwise / norm rows
         small16 = a.qin == 16 && a.qout == 16 &&
                   (a.combine == 0 || a.combine == 2 || a.combine == 3 ||
-                   (a.combine == 1 && ((a.h_by_value && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order) ||
+                   (a.combine == 1 && (((a.h_by_value || eval_walk_) && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order) ||
                                        (a.cmb.order == 1 && !(a.cmb.err_partials && (a.cmb.out2 || a.cmb.out2_nchw))))));
         // (a reverse-sweep row that falls to the shared epilogue must not carry relocatable pointers: the adaptive drivers keep to two
         // constant-coefficient targets)
