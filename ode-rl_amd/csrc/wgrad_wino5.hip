@@ -178,7 +178,11 @@ __global__ __launch_bounds__(512, 1) void wgrad32_wino5_kernel(const WgradPair* 
   for (int it = 0; it < n_it; ++it) {
     transform();
     __builtin_amdgcn_s_barrier();  // W and V of this chunk are in LDS
-    if (it + 1 < n_it) issue(it + 1);
+    // The 30 scattered 8-byte loads of the next unit take a wave 2400 - 3800 cycles to ISSUE (in-kernel stamps,
+    // tools/experiments/w5_stamps.py: the address unit takes ~16 cycles per wave instruction and eight waves queue up), during which
+    // it issues no MFMA.  So the two waves of a SIMD take turns: waves 4-7 issue their loads first while waves 0-3 have the matrix
+    // core, then the other way round (66.7 -> 61.5 us per launch).
+    if (wave >= 4 && it + 1 < n_it) issue(it + 1);
     // fragment of K-step s: tile 4 s + kq, channel 16 blk + m -> quad (4 blk + m / 4) ^ swz(tile), float m % 4
     const char* const fw = smem + (9 * pg) * kW5Plane + (m & 3) * 4;
 #pragma unroll 1
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(512, 1) void wgrad32_wino5_kernel(const WgradPair* 
         acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, b1, acc[p][1], 0, 0, 0);
       }
     }
+    if (wave < 4 && it + 1 < n_it) issue(it + 1);
     if (it + 1 < n_it) issue_grad();
     __builtin_amdgcn_s_barrier();  // every wave is done reading before the next chunk is written
   }
