@@ -72,8 +72,18 @@ __device__ void adj_sums4(const float* base, int stride, const int* which, int c
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (w < count) {
     const float* v = base + (size_t)which[w] * stride;
-    float s = 0.0f;
-    for (int i = lane; i < n; i += 64) s += v[i];
+    // four independent chains: a lane's 64 strided loads (n = 64 partials per sample x 64 samples) were one dependent chain of L2
+    // round trips on the critical path of every tick
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int i = lane;
+    for (; i + 192 < n; i += 256) {
+      s0 += v[i];
+      s1 += v[i + 64];
+      s2 += v[i + 128];
+      s3 += v[i + 192];
+    }
+    for (; i < n; i += 64) s0 += v[i];
+    float s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) sh[w] = s;
