@@ -161,6 +161,176 @@ __device__ __forceinline__ void wgrad_wino_walk(const WgradPair* __restrict__ ta
   }
 }
 
+// ---- second version (round 3): units of ONE tile row (8 tiles), two LDS buffers.
+// The first version's unit (16 tiles, one buffer) runs transform | barrier | multiply | barrier: the matrix core idles while the
+// operands are transformed and written (12,700 cycles per 16 tiles against 8,192 of MFMA work at two waves per SIMD).  Here the
+// operands of unit u + 1 are transformed into the other buffer while unit u is multiplied -- one barrier per unit --, and the
+// transform / load work of a unit falls to one of two wave groups in turn (even units: waves 0, 1 gradients and 6, 7 activations; odd
+// units: waves 2, 3 and 4, 5): one transforming wave per SIMD and unit.  LDS: 2 x ([xi 16][tile 8][quad 16] x 16 B per operand) =
+// 128 KiB.  Same accumulators, same slab, same sums: the results differ from the first version's only by the order of the tile sum.
+constexpr int kW2Plane = 8 * 16 * 16;          // one position of one operand: [tile 8][quad 16] x 16 B
+constexpr int kW2Operand = 16 * kW2Plane;      // 32 KiB
+constexpr int kW2Buf = 2 * kW2Operand;         // W | V of one unit
+constexpr int kW2Lds = 2 * kW2Buf;
+
+template <bool ACT>
+__device__ __forceinline__ void wgrad_wino_walk2(const WgradPair* __restrict__ table, int n_eval, int esplit, float* __restrict__ slabs,
+                                                 int g_quad0, int g_quads, int a_quad0, int a_quads, char* smem, int lane, int wave) {
+  const int b = blockIdx.x, es = blockIdx.y;
+  // transforms the units of this parity: gradients waves 0, 1 (even units) / 2, 3 (odd), activations waves 6, 7 (even) / 4, 5 (odd) --
+  // in every unit each SIMD (waves w and w + 4) has exactly one transforming wave, whose partner has the matrix core meanwhile
+  const int group = ((wave >> 1) & 1) ^ (ACT ? 1 : 0);
+  const int quad = 8 * (wave & 1) + (lane >> 3);     // transform role: channel quad, tile of the row
+  const int tx = lane & 7;
+  // quads XOR-swizzled by the tile (as in the first version: (tile & 3) into the upper, tile >> 2 into the lower bits)
+  const int wr_off = (ACT ? kW2Operand : 0) + tx * 256 + ((quad ^ ((tx & 3) << 2) ^ (tx >> 2)) * 16);   // + buffer + xi * kW2Plane
+  const int m = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[x][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  const int n_mine = es < n_eval ? (n_eval - es + esplit - 1) / esplit : 0;
+  const int n_it = n_mine * 8;  // (evaluation, tile row) pairs
+  constexpr int NR = ACT ? 16 : 4;
+  f32x4 raw[NR];
+  float esc_raw = 0.0f;
+  auto issue = [&](int it) {  // the global loads of unit `it` into raw
+    const int e = es + (it >> 3) * esplit, ty = it & 7;
+    const WgradPair pr = table[e];
+    esc_raw = pr.scale;
+    if (!ACT) {
+      const __amdgpu_buffer_rsrc_t rg = make_rsrc(pr.g + ((size_t)b * g_quads + g_quad0) * 4 * kPix, 64 * kPix * 4);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) raw[(2 * k + l) % NR] = bufload(rg, quad * 4096 + ((2 * ty + k) * 16 + 2 * tx + l) * 16);
+    } else {
+      const __amdgpu_buffer_rsrc_t ra = make_rsrc(pr.a + ((size_t)b * a_quads + a_quad0) * 4 * kPix, 64 * kPix * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const int row = 2 * ty - 1 + k, col = 2 * tx - 1 + l;
+          const bool in = row >= 0 && row < kHW && col >= 0 && col < kHW;
+          raw[(4 * k + l) % NR] = bufload(ra, in ? quad * 4096 + (row * 16 + col) * 16 : kOobOffset);  // out of range: zeros
+        }
+    }
+  };
+  auto transform = [&](char* buf) {  // raw -> this thread's 16 positions of one operand in `buf`
+    char* const wr = buf + wr_off;
+    if (!ACT) {
+      const f32x4 d00 = raw[0] * esc_raw, d01 = raw[1 % NR] * esc_raw, d10 = raw[2 % NR] * esc_raw, d11 = raw[3 % NR] * esc_raw;
+      bsum += (d00 + d01) + (d10 + d11);
+      const f32x4 t[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *(f32x4*)(wr + (4 * i + 0) * kW2Plane) = t[i][0];
+        *(f32x4*)(wr + (4 * i + 1) * kW2Plane) = t[i][0] + t[i][1];
+        *(f32x4*)(wr + (4 * i + 2) * kW2Plane) = t[i][0] - t[i][1];
+        *(f32x4*)(wr + (4 * i + 3) * kW2Plane) = -t[i][1];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 T[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const f32x4 r0 = raw[l % NR], r1 = raw[(4 + l) % NR], r2 = raw[(8 + l) % NR], r3 = raw[(12 + l) % NR];
+          T[l] = i == 0 ? r0 - r2 : (i == 1 ? r1 + r2 : (i == 2 ? r2 - r1 : r1 - r3));
+        }
+        *(f32x4*)(wr + (4 * i + 0) * kW2Plane) = T[0] - T[2];
+        *(f32x4*)(wr + (4 * i + 1) * kW2Plane) = T[1] + T[2];
+        *(f32x4*)(wr + (4 * i + 2) * kW2Plane) = T[2] - T[1];
+        *(f32x4*)(wr + (4 * i + 3) * kW2Plane) = T[1] - T[3];
+      }
+    }
+  };
+
+  // prologue: unit 0 (group 0) into buffer 0; group 1 already fetches unit 1, group 0 unit 2
+  if (n_it > 0) {
+    if (group == 0) {
+      issue(0);
+      transform(smem);
+      if (2 < n_it) issue(2);
+    } else if (1 < n_it) {
+      issue(1);
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+  for (int it = 0; it < n_it; ++it) {
+    // the operands of unit it + 1 into the other buffer (by the group of its parity), and that group's loads of unit it + 3
+    if (it + 1 < n_it && ((it + 1) & 1) == group) {
+      transform(smem + ((it + 1) & 1) * kW2Buf);
+      if (it + 3 < n_it) issue(it + 3);
+    }
+    // fragment of K-step s: tile 4 s + kq, channel 16 blk + m  ->  quad (4 blk + m / 4) ^ (kq << 2) ^ s, float m % 4
+    const char* fw = smem + (it & 1) * kW2Buf + (2 * wave) * kW2Plane + kq * 256 + (m & 3) * 4;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float af[4], bf[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          const int off = x * kW2Plane + s * 1024 + (((4 * blk + (m >> 2)) ^ (kq << 2) ^ s) * 16);
+          af[blk] = *(const float*)(fw + off);
+          bf[blk] = *(const float*)(fw + kW2Operand + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[x][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[x][i][j], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_barrier();  // unit it is read, unit it + 1 is written
+  }
+
+  float* slab = slabs + (size_t)(b * esplit + es) * kWgradSlabFloats;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // D row = 4 kq + r -> co, D col = m -> ci
+          slab[((size_t)(2 * wave + x) * 64 + 16 * i + 4 * kq + r) * 64 + 16 * j + m] = acc[x][i][j][r];
+  // bias sums: a channel quad's tiles were transformed by one wave of EACH group (even / odd tile rows): group 1's halves through LDS
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!ACT) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      bv[c] = v;
+    }
+    if (group == 1 && tx == 0) *(f32x4*)(smem + quad * 16) = f32x4{bv[0], bv[1], bv[2], bv[3]};
+  }
+  __builtin_amdgcn_s_barrier();
+  if (!ACT && group == 0 && tx == 0) {
+    const f32x4 o = *(const f32x4*)(smem + quad * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) slab[16 * 64 * 64 + 4 * quad + c] = bv[c] + o[c];
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad64_wino2_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
+                                                               float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
+                                                               int a_quads) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < 4) wgrad_wino_walk2<false>(table, n_eval, esplit, slabs, g_quad0, g_quads, a_quad0, a_quads, smem, lane, wave);
+  else          wgrad_wino_walk2<true>(table, n_eval, esplit, slabs, g_quad0, g_quads, a_quad0, a_quads, smem, lane, wave);
+}
+
 __global__ __launch_bounds__(512, 1) void wgrad64_wino_kernel(const WgradPair* __restrict__ table, int n_eval, int esplit,
                                                               float* __restrict__ slabs, int g_quad0, int g_quads, int a_quad0,
                                                               int a_quads, int dbg) {
@@ -207,16 +377,25 @@ int launch_wgrad_wino(const WgradPair* table_dev, int n_eval, int batch, int esp
   static const bool off = [] { const char* e = getenv("ODEHIP_WGRAD_WINO"); return e && e[0] == '0'; }();
   if (off) return 1;
   static const int dbg = [] { const char* e = getenv("ODEHIP_WW_DBG"); return e ? atoi(e) : 0; }();  // ablations (timing only)
-  static bool attr_set = false;
+  static bool attr_set = false, attr_set2 = false;
   if (!attr_set) {
     ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  static const bool v1 = [] { const char* e = getenv("ODEHIP_WGRAD_WINO_V1"); return e && e[0] == '1'; }();   // the one-buffer version (A/B)
+  if (!attr_set2) {
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wgrad64_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set2 = true;
+  }
   float* const sum = slabs + (size_t)batch * esplit * kWgradSlabFloats;  // the slab region is sized for one more slab
   for (int co0 = 0; co0 < cout; co0 += 64)
     for (int ci0 = 0; ci0 < cin; ci0 += 64) {
-      hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(batch, esplit), dim3(512), kWwLds, stream, table_dev, n_eval, esplit, slabs, co0 / 4,
-                         cout / 4, ci0 / 4, cin / 4, dbg);
+      if (v1 || dbg)
+        hipLaunchKernelGGL(wgrad64_wino_kernel, dim3(batch, esplit), dim3(512), kWwLds, stream, table_dev, n_eval, esplit, slabs, co0 / 4,
+                           cout / 4, ci0 / 4, cin / 4, dbg);
+      else
+        hipLaunchKernelGGL(wgrad64_wino2_kernel, dim3(batch, esplit), dim3(512), kW2Lds, stream, table_dev, n_eval, esplit, slabs, co0 / 4,
+                           cout / 4, ci0 / 4, cin / 4);
       launch_slab_sum4(slabs, batch * esplit, kWgradSlabFloats, kWgradSlabFloats, sum, stream);
       hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(16), dim3(256), 0, stream, sum, dw, db, cin, co0, ci0);
     }
