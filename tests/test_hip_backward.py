@@ -144,7 +144,7 @@ def test_adjoint_matches_oracle_adjoint(cuda, method, T):
             f.gradient_net[i].bias.copy_(torch.where(torch.arange(64) % 2 == 0, 2.5, -2.5))
         f.gradient_net[8].weight.mul_(4.0)
     sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
-    z0, t, gout = _case(7, T, 3)
+    z0, t, gout = _case(7, T, batch)
     ws, bs = rm.split_convnet_state(sd, "gradient_net.")
     ws = [w.clone().requires_grad_(True) for w in ws]
     bs = [b.clone().requires_grad_(True) for b in bs]
@@ -161,11 +161,12 @@ def test_adjoint_matches_oracle_adjoint(cuda, method, T):
         assert rel_l2(c.bias.grad, gb) <= 1e-4
 
 
-@pytest.mark.parametrize("rtol,atol,T", [(1e-3, 1e-4, 4), (1e-5, 1e-6, 3), (1e-3, 1e-4, 2)])
-def test_dopri5_adjoint_matches_oracle_adjoint(cuda, rtol, atol, T):
+@pytest.mark.parametrize("rtol,atol,T,batch", [(1e-3, 1e-4, 4, 3), (1e-5, 1e-6, 3, 3), (1e-3, 1e-4, 2, 3), (1e-3, 1e-4, 3, 20)])
+def test_dopri5_adjoint_matches_oracle_adjoint(cuda, rtol, atol, T, batch):
     """Adaptive adjoint (BASELINE.json configs[2]): odeint_adjoint(method="dopri5", adjoint_options={"norm": "seminorm"})
     against the restatement of torchdiffeq's adjoint with the same norm, on kink-free dynamics.  Same accepted/rejected
-    step sequence (counts equal) and rel-L2 <= 1e-4 on every gradient."""
+    step sequence (counts equal) and rel-L2 <= 1e-4 on every gradient.  batch 20: above the sixteen-workgroup walk's limit, i.e. the
+    four-workgroup adaptive walk the B = 64 configurations run on (its elementwise rows, 4 x 64 partials per sample)."""
     import ode_rl_amd
     from oracle import reference_modules as rm
     from oracle import torchdiffeq_ref
@@ -240,14 +241,14 @@ def _kink_free():
     return f, {k: v.detach().clone() for k, v in f.state_dict().items()}
 
 
-@pytest.mark.parametrize("rtol,atol,T,first_step", [(1e-3, 1e-4, 4, 0.02), (1e-5, 1e-6, 3, 0.01), (1e-4, 1e-5, 2, 0.3)])
-def test_dopri5_backward_matches_autograd_through_oracle(cuda, rtol, atol, T, first_step):
+@pytest.mark.parametrize("rtol,atol,T,first_step,batch", [(1e-3, 1e-4, 4, 0.02, 3), (1e-5, 1e-6, 3, 0.01, 3), (1e-4, 1e-5, 2, 0.3, 3), (1e-4, 1e-5, 2, 0.3, 20)])
+def test_dopri5_backward_matches_autograd_through_oracle(cuda, rtol, atol, T, first_step, batch):
     """loss.backward() through odeint(method="dopri5") -- the reference's default training path -- against autograd
     through the restatement.  options={"first_step": dt} makes every step size a constant of the graph, so the two must
     agree to round-off: rel-L2 <= 1e-4 on every gradient (kink-free dynamics).  (0.3 forces rejected first attempts.)"""
     import ode_rl_amd
     f, sd = _kink_free()
-    z0, t, gout = _case(7, T, 3)
+    z0, t, gout = _case(7, T, batch)   # (batch 20: the four-workgroup adaptive walk of the B = 64 configurations; <= 16: the sixteen-workgroup one)
     stats = {}
     ref = _oracle_grads(sd, z0, t, gout, "dopri5", rtol=rtol, atol=atol, options={"first_step": first_step}, stats=stats)
     assert ref[4] > 0.5

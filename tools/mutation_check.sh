@@ -15,7 +15,7 @@ SED[codec_enc_slope]='s/v = w2\[((size_t)co \* kEncMid + 4 \* kq + j) \* 9 + tap
 SED[wino5_bt_coef]='s/out\[0\] = fma2(4.0f, in\[0\], fma2(-5.0f, in\[2\], in\[4\]));/out[0] = fma2(4.0f, in[0], fma2(-4.0f, in[2], in[4]));/'      # F(2x2,5x5): B^T row 0: -5 -> -4
 SED[wino5_at_coef]='s/^  return i == 0 ? 0.0f : (i == 1 ? 1.0f : (i == 2 ? -1.0f : (i == 3 ? 2.0f : (i == 4 ? -2.0f : 1.0f))));/  return i == 0 ? 0.0f : (i == 1 ? 1.0f : (i == 2 ? -1.0f : (i == 3 ? 2.0f : (i == 4 ? -1.0f : 1.0f))));/'    # F(2x2,5x5): A^T row 1: -2 -> -1
 SED[wgrad_wino_g]='s/const float hs = 0.5f \* (u\[1\]\[j\] + u\[2\]\[j\]), hd = 0.5f \* (u\[1\]\[j\] - u\[2\]\[j\]);/const float hs = 0.5f * (u[1][j] + u[2][j]), hd = 0.4f * (u[1][j] - u[2][j]);/'   # Winograd-domain weight gradient: one G entry 0.5 -> 0.4
-SED[wgrad_wino_at]='s/\*(f32x4\*)(wr + (4 \* i + 2) \* kWwPlane) = t\[i\]\[0\] - t\[i\]\[1\];/*(f32x4*)(wr + (4 * i + 2) * kWwPlane) = t[i][0] + t[i][1];/'   # ... and one sign of A dY A^T
+SED[wgrad_wino_at]='s/\*(f32x4\*)(wr + (4 \* i + 2) \* kW2Plane) = t\[i\]\[0\] - t\[i\]\[1\];/*(f32x4*)(wr + (4 * i + 2) * kW2Plane) = t[i][0] + t[i][1];/'   # ... and one sign of A dY A^T
 # ---- round 3: the adaptive walk, the device-driven adjoint, the saving forward, the 16-workgroup walk
 SED[adapt_combine_ccur]='s/      d_cA = m.c1\[np\];/      d_cA = m.c1[np] * 1.01f;/'                                  # adaptive walk: weight of the stage's own k in an order-1 combine
 SED[adapt_ew_coef]='s/    const float c1 = (m.c_dev ? ((ConstF\*)m.c_dev)\[j\] : m.c1\[j\]) \* hs;/    const float c1 = (m.c_dev ? ((ConstF*)m.c_dev)[j] : m.c1[j]) * hs * 1.01f;/'   # elementwise rows of the walk
@@ -31,6 +31,7 @@ TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics te
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
+    if [ -n "${MUT_ONLY:-}" ] && [[ ! " $MUT_ONLY " =~ " $m " ]]; then continue; fi
     d=$MUT/$m
     rm -rf "$d"; mkdir -p "$d/ode-rl_amd/csrc" "$d/include"
     cp "$ROOT"/ode-rl_amd/csrc/*.hip "$ROOT"/ode-rl_amd/csrc/*.h "$ROOT"/ode-rl_amd/csrc/Makefile "$d/ode-rl_amd/csrc/"
