@@ -43,6 +43,13 @@ def test_structure_predicates_on_cpu_modules():
     assert not hip_ops.frame_encoder_supported(Encoder(16, 64, 3, nonlinear="leaky_relu").encoder)   # the reference's n_downs = 3 shape
     assert not hip_ops.frame_encoder_supported(_encoder(1, 48, 1).encoder)
     assert not hip_ops.frame_encoder_supported(Encoder(1, 64, 2, nonlinear="relu").encoder)
+    # the backward kernels' narrower set: one frame channel, 32 / 64 latent channels (everything else: the library under autograd)
+    assert hip_ops.frame_encoder_backward_supported(_encoder(1, 64, 1).encoder) and hip_ops.frame_decoder_backward_supported(_decoder(64, 1, 1).decoder)
+    assert hip_ops.frame_encoder_backward_supported(_encoder(1, 32, 1).encoder) and hip_ops.frame_decoder_backward_supported(_decoder(32, 1, 1).decoder)
+    for lat, ch in ((128, 1), (64, 3)):
+        assert hip_ops.frame_encoder_supported(_encoder(ch, lat, 1).encoder) and not hip_ops.frame_encoder_backward_supported(_encoder(ch, lat, 1).encoder)
+        assert hip_ops.frame_decoder_supported(_decoder(lat, ch, 1).decoder) and not hip_ops.frame_decoder_backward_supported(_decoder(lat, ch, 1).decoder)
+    assert not hip_ops.frame_encoder_backward_supported(_decoder(64, 1, 1).decoder) and not hip_ops.frame_decoder_backward_supported(_encoder(1, 64, 1).encoder)
 
 
 @pytest.mark.gpu
