@@ -144,7 +144,7 @@ def test_adjoint_matches_oracle_adjoint(cuda, method, T):
             f.gradient_net[i].bias.copy_(torch.where(torch.arange(64) % 2 == 0, 2.5, -2.5))
         f.gradient_net[8].weight.mul_(4.0)
     sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
-    z0, t, gout = _case(7, T, batch)
+    z0, t, gout = _case(7, T, 3)
     ws, bs = rm.split_convnet_state(sd, "gradient_net.")
     ws = [w.clone().requires_grad_(True) for w in ws]
     bs = [b.clone().requires_grad_(True) for b in bs]
@@ -177,7 +177,7 @@ def test_dopri5_adjoint_matches_oracle_adjoint(cuda, rtol, atol, T, batch):
             f.gradient_net[i].bias.copy_(torch.where(torch.arange(64) % 2 == 0, 2.5, -2.5))
         f.gradient_net[8].weight.mul_(4.0)
     sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
-    z0, t, gout = _case(7, T, 3)
+    z0, t, gout = _case(7, T, batch)
     ws, bs = rm.split_convnet_state(sd, "gradient_net.")
     ws = [w.clone().requires_grad_(True) for w in ws]
     bs = [b.clone().requires_grad_(True) for b in bs]
