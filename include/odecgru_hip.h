@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 9 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 10 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -56,7 +56,8 @@ enum {
   ODEHIP_EINVAL = -1,   /* bad shape / argument (the Python side raises ValueError) */
   ODEHIP_EHIP = -2,     /* a HIP runtime call failed */
   ODEHIP_ENOTCONV = -3, /* adaptive solver hit max_num_steps / dt underflow (AssertionError in torchdiffeq) */
-  ODEHIP_ENAN = -4      /* non-finite state (the reference asserts: modules/ODEConvGRUCell.py:56,59) */
+  ODEHIP_ENAN = -4,     /* non-finite state (the reference asserts: modules/ODEConvGRUCell.py:56,59) */
+  ODEHIP_ETRUNC = -5    /* asynchronous dopri5: the attempts enqueued by _start did not finish the solve (see there) */
 };
 
 /* fixed-grid methods of torchdiffeq (_impl/fixed_grid.py); rk4 is the 3/8 rule */
@@ -371,10 +372,14 @@ int odehip_odeint_dopri5_backward_saved(const odehip_convstack* f, const odehip_
  * completion -- the host cannot enqueue the work BEHIND the solver (decoder, loss, the backward pass) meanwhile, and in a whole
  * training step the device then idles while ~600 launches are enqueued.  odehip_odeint_dopri5_start takes _saving's arguments
  * (max_accept = 0: nothing is kept for a backward pass), enqueues `attempts` attempted steps (those queued behind completion
- * return at once) and comes back WITHOUT waiting: no stats, no status.  odehip_odeint_dopri5_collect(token) waits for the device
- * (normally long done), enqueues further attempts should the solve need them, and reports what the synchronous call reports --
- * including ODEHIP_ENOTCONV / ODEHIP_ENAN, i.e. an error surfaces at collect time.  Everything start was given (workspace, out,
- * z0) must stay untouched until collect; at most 4 solves may be pending; not available under exact-global step control. */
+ * return at once) and comes back WITHOUT waiting: no stats, no status.  The caller enqueues its consumers of `out` behind this
+ * call, so the attempts enqueued HERE are all the solve ever gets: behind the last one sits a seal kernel which, if the solve is
+ * not done, fills the frames it has not reached with NaN (ABI 10; before, collect enqueued the missing attempts behind the
+ * consumers, which had then read uninitialised frames).  odehip_odeint_dopri5_collect(token) waits for the device (normally long
+ * done) and reports what the synchronous call reports -- including ODEHIP_ENOTCONV / ODEHIP_ENAN, i.e. an error surfaces at
+ * collect time -- or ODEHIP_ETRUNC for a sealed, unfinished solve (stats_host[3] = the attempts that were enqueued; stats are
+ * filled in that case too, so the caller can size its retry).  Everything start was given (workspace, out, z0) must stay
+ * untouched until collect; at most 4 solves may be pending; not available under exact-global step control. */
 int odehip_odeint_dopri5_start(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
                                float rtol, float atol, double first_step, int max_steps, float* out_nchw, int max_accept,
                                int attempts, int* token_out, void* workspace, size_t workspace_bytes, void* stream);

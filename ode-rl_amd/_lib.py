@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
-ABI_VERSION = 9   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
+ABI_VERSION = 10   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
 MAX_LAYERS = 8
 MAX_STAGES = 7
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
@@ -95,6 +95,12 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, cty
 
 class OdeHipError(RuntimeError):
     pass
+
+
+class AsyncSolveTruncated(OdeHipError):
+    """An asynchronous dopri5 solve needed more attempted steps than were enqueued up front (ODEHIP_ETRUNC): the frames it had not
+    reached are NaN and everything computed from them since is invalid.  The next asynchronous solve enqueues more; a training step
+    can simply be repeated (nothing has been applied to the parameters)."""
 
 
 _lib = None
@@ -280,4 +286,6 @@ def check(rc):
         raise ValueError(msg)
     if rc in (-3, -4):
         raise AssertionError(msg)
+    if rc == -5:
+        raise AsyncSolveTruncated(msg)
     raise OdeHipError(f"odehip status {rc}: {msg}")

@@ -210,11 +210,13 @@ class _AdjointDopri5(torch.autograd.Function):
             out, pending = hip_ops.odeint_dopri5_start(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"], first_step=cfg["first_step"],
                                                        max_steps=cfg["max_num_steps"])
             last_stats._bind(pending)
+            ctx.pending = pending
         else:
             out, stats = hip_ops.odeint_dopri5(stack, y0.detach(), t_host, cfg["rtol"], cfg["atol"],
                                                first_step=cfg["first_step"], max_steps=cfg["max_num_steps"])
             last_stats.clear()
             last_stats.update(stats)
+            ctx.pending = None
         ctx.stack, ctx.t_host, ctx.cfg = stack, t_host, cfg
         ctx.versions = tuple(p._version for p in params)
         ctx.params = params
@@ -227,6 +229,9 @@ class _AdjointDopri5(torch.autograd.Function):
         if tuple(p._version for p in ctx.params) != ctx.versions:
             raise RuntimeError("a parameter of the ODE dynamics was modified in place between forward and backward")
         (y_traj,) = ctx.saved_tensors
+        if ctx.pending is not None:   # the forward solve's outcome: an error (or a sealed, unfinished solve) must stop the adjoint here
+            ctx.pending.collect()
+            ctx.pending = None
         cfg = ctx.cfg
         stats = {}
         gz0, gws, gbs = hip_ops.odeint_adjoint_dopri5_backward(ctx.stack, ctx.t_host, y_traj, grad_out, cfg["adjoint_rtol"],

@@ -54,7 +54,8 @@ constexpr int kMailboxBytes = 65536;
 constexpr int kLogCap = (kMailboxBytes - 64) / 16;
 struct Mailbox {  // pinned host memory, written by the controller with system-scope stores
   volatile int steps_done, done, status, n_accept, n_reject, nfe, save_ok;
-  int pad_[9];
+  volatile int truncated;   // asynchronous solve: the attempts enqueued by start() did not finish it (seal_kernel)
+  int pad_[8];
   volatile double log[kLogCap][2];  // (t0, dt) of every accepted step, in order (what a backward pass re-integrates)
 };
 
@@ -306,6 +307,21 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a, long long n4,
   }
 }
 
+// The SEAL of an asynchronous solve (odehip_odeint_dopri5_start): enqueued behind the last attempt start() enqueues.  The caller has
+// been handed `out` and goes on enqueueing its consumers (decoder, loss, the backward pass) behind this kernel, so nothing enqueued
+// LATER can still complete the trajectory for them.  If the solve is not done here, the frames it has not reached are filled with NaN
+// -- the consumers then compute NaN instead of reading uninitialised memory -- and the mailbox says so: collect() fails with
+// ODEHIP_ETRUNC instead of carrying on behind the consumers' backs.
+__global__ __launch_bounds__(256) void seal_kernel(const DopriState* st, Mailbox* mb, float* out_nchw, long long state_floats) {
+  if (st->done) return;
+  const int j0 = st->j_next, nt = st->n_times;
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store((int*)&mb->truncated, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const long long n = (long long)(nt - j0) * state_floats;
+  float* o = out_nchw + (long long)j0 * state_floats;
+  const float nan = __builtin_nanf("");
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = nan;
+}
+
 struct DoublePack {
   double v[32];
 };
@@ -378,7 +394,7 @@ struct D5Ctx {
   float *part0 = nullptr, *ping = nullptr, *pong = nullptr, *xs = nullptr, *y = nullptr, *y1 = nullptr, *k[7] = {};
   unsigned* psync = nullptr;
   unsigned long long* reloc = nullptr;
-  bool saving = false, global_norm = false;
+  bool saving = false, global_norm = false, partials64 = false;
   size_t bl_st = 0, bl_hid = 0;   // BwdLayout::st / hid / NH of the saving slots
   int bl_nh = 0;
   FinishArgs fa;
@@ -464,6 +480,12 @@ static int d5_attempt(D5Ctx& x) {
   }
   if (x.saving) persist.set_device_steering(nullptr, x.reloc);
   if ((rc = persist.finish(nullptr, nullptr, nullptr, x.batch, x.psync, f->ks, x.stream, /*sync_is_zero=*/true)) != ODEHIP_OK) return rc;
+  if (x.partials64 && !persist.launched()) {
+    // the controller sums 64 error-norm partials per sample (the sixteen-workgroup walk's); a refused launch has just been replayed
+    // as per-layer launches, which write 16: the norm of this attempt is not the solver's
+    set_error("odeint_dopri5: the persistent walk became unavailable during the solve (its error-norm partials are laid out for it)");
+    return ODEHIP_EHIP;
+  }
   if (x.global_norm) {
     const float* arr[1] = {x.part0};
     const int lens[1] = {x.n_conv_partials};
@@ -786,6 +808,7 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   for (int i = 0; i < 7; ++i) cx.k[i] = k[i];
   cx.psync = psync; cx.reloc = reloc;
   cx.saving = saving; cx.global_norm = global_norm;
+  cx.partials64 = n_conv_partials == batch * 64 && n_conv_partials != batch * (C / 32) * 2 * 4;
   cx.bl_st = BL.st; cx.bl_hid = BL.hid; cx.bl_nh = BL.NH;
   cx.fa = fa;
   cx.n4 = n4;
@@ -794,6 +817,8 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
     // waiting for the device; odehip_odeint_dopri5_collect() reads the outcome later and carries on should the solve need more
     for (int i = 0; i < async_attempts; ++i)
       if ((rc = d5_attempt(cx)) != ODEHIP_OK) return rc;
+    hipLaunchKernelGGL(seal_kernel, dim3(1024), dim3(256), 0, stream, state, cx.mb, out_nchw, (long long)st_f);
+    ODEHIP_CHECK_HIP(hipGetLastError());
     cx.in_use = true;
     *token_out = slot;
     return ODEHIP_OK;
@@ -802,9 +827,11 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   return d5_collect(cx, stats_host, accepted_host, accepted_cap, saved_out);
 }
 
-// ---- the asynchronous pair (ABI 8).  start = odehip_odeint_dopri5_saving's arguments (max_accept = 0: nothing is kept) + how many
-// attempted steps to enqueue before returning; nothing is waited for and no outcome is reported.  collect(token) waits for the
-// device (normally long done), enqueues further attempts if the solve is not finished, and returns what the synchronous call
+// ---- the asynchronous pair (ABI 8; sealed since ABI 10).  start = odehip_odeint_dopri5_saving's arguments (max_accept = 0: nothing
+// is kept) + how many attempted steps to enqueue before returning; nothing is waited for and no outcome is reported.  Behind the
+// last attempt start() enqueues the SEAL: the caller's consumers of `out` are enqueued behind start(), so attempts enqueued any later
+// could not complete the trajectory for them -- a solve that is not done at the seal gets its unreached frames NaN-filled and
+// collect() reports ODEHIP_ETRUNC.  collect(token) waits for the device (normally long done) and returns what the synchronous call
 // returns (status code, stats, accepted-step log, saved flag).  Everything the start call was given (workspace, out, z0) must stay
 // untouched until collect; at most four solves may be pending.
 extern "C" int odehip_odeint_dopri5_start(const odehip_convstack* f, const float* z0_nchw, const double* t_host, int n_times, int batch,
@@ -829,7 +856,31 @@ extern "C" int odehip_odeint_dopri5_collect(int token, int* stats_host, double* 
     if (stats_host) stats_host[0] = stats_host[1] = stats_host[2] = stats_host[3] = 0;
     return ODEHIP_OK;
   }
-  int rc = d5_run_to_done(cx);
-  if (rc != ODEHIP_OK) return rc;
+  // the attempts start() enqueued and the seal behind them are all this solve ever gets: wait for them, enqueue nothing
+  cx.t_progress = now_s();
+  while (cx.mb->steps_done < cx.enq) {
+    if (cx.mb->steps_done != cx.seen) {
+      cx.seen = cx.mb->steps_done;
+      cx.t_progress = now_s();
+    }
+    if (now_s() - cx.t_progress > 120.0) {
+      set_error("odeint_dopri5_collect: no progress from the device for 120 s (steps done %d of %d enqueued)", cx.mb->steps_done, cx.enq);
+      return ODEHIP_EHIP;
+    }
+  }
+  if (!cx.mb->done) {
+    // the seal runs right behind the last controller: its verdict is at most a kernel away
+    ODEHIP_CHECK_HIP(hipStreamSynchronize(cx.stream));
+    if (stats_host) {
+      stats_host[0] = cx.mb->nfe;
+      stats_host[1] = cx.mb->n_accept;
+      stats_host[2] = cx.mb->n_reject;
+      stats_host[3] = cx.enq;
+    }
+    set_error("odeint_dopri5_collect: the solve was not finished by the %d attempted steps start() enqueued (%d accepted, %d rejected "
+              "so far); the frames it had not reached were NaN-filled, because the work enqueued behind start() has already consumed "
+              "`out`.  Start again with more attempts, or use the synchronous call", cx.enq, cx.mb->n_accept, cx.mb->n_reject);
+    return ODEHIP_ETRUNC;
+  }
   return d5_collect(cx, stats_host, accepted_host, accepted_cap, saved_out);
 }

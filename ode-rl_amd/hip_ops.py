@@ -484,6 +484,7 @@ LOG_CAP = 2048   # accepted steps the forward reports back (the backward pass re
 
 def odeint_dopri5(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0, negate=False):
     """Adaptive dopri5 trajectory; returns ((T,B,C,16,16), stats dict).  stats["accepted"] = [(t0, dt), ...]."""
+    collect_pending_solves()   # an asynchronous solve still in flight owns the shared ("dopri5", ...) workspace
     require_device_tensor(z0, "y0")
     desc = stack.refresh()
     z0 = z0.contiguous()
@@ -517,7 +518,8 @@ _dopri5_save_slots = 8   # slots of a saving forward's workspace; doubled (up to
 # backward pass, at the first look into ode_rl_amd.last_stats, or at the next dopri5 call.  Off by default: torchdiffeq raises such
 # errors from odeint() itself, and so does the synchronous path.
 _async_dopri5 = os.environ.get("ODEHIP_DOPRI5_ASYNC") == "1"
-_async_attempts = 4      # attempted steps enqueued up front; follows what the previous solve needed
+_async_attempts = 8      # attempted steps enqueued up front; follows what the previous solve needed (+ margin)
+ASYNC_ATTEMPTS_MAX = 256
 _pending_solves = []     # PendingDopri5 objects not collected yet
 
 
@@ -525,9 +527,9 @@ def set_async_dopri5(on=True):
     """Switch the asynchronous dopri5 forward on / off (see above); returns the previous setting."""
     global _async_dopri5
     was = _async_dopri5
-    if not on:
-        collect_pending_solves()
     _async_dopri5 = bool(on)
+    if not on:
+        collect_pending_solves()   # may raise a pending solve's error; the switch is already off then
     return was
 
 
@@ -559,6 +561,12 @@ class PendingDopri5:
             lib = _lib.load()
             try:
                 _lib.check(lib.odehip_odeint_dopri5_collect(int(self.token), stats, log, LOG_CAP, ctypes.byref(saved)))
+            except _lib.AsyncSolveTruncated as e:
+                # the attempts enqueued up front did not finish the solve and its consumers have read NaN frames: the NEXT solve gets
+                # twice as many (the caller repeats its step; train_batch does)
+                _async_attempts = min(ASYNC_ATTEMPTS_MAX, max(2 * int(stats[3]), _async_attempts))
+                self._result = e
+                raise
             except BaseException as e:
                 self._result = e
                 raise
@@ -567,7 +575,12 @@ class PendingDopri5:
             k = min(int(stats[1]), LOG_CAP)
             if self.slots and int(stats[1]) > self.slots:
                 _dopri5_save_slots = min(64, max(2 * self.slots, int(stats[1]) + 2))
-            _async_attempts = max(2, min(16, int(stats[1]) + int(stats[2]) + 1))
+            # what this solve needed plus a margin of a quarter (at least 2): an attempt queued behind `done` costs three empty
+            # launches, an attempt too few costs the step (AsyncSolveTruncated).  Never below what the last solve was given unless
+            # it used less than half of it -- the count drifts slowly as the dynamics train
+            used = int(stats[1]) + int(stats[2])
+            want = used + max(2, used // 4)
+            _async_attempts = max(4, min(ASYNC_ATTEMPTS_MAX, want if want > _async_attempts or 2 * want < _async_attempts else _async_attempts))
             st = {"nfe": stats[0], "n_accept": stats[1], "n_reject": stats[2], "attempts_enqueued": stats[3],
                   "accepted": [(log[2 * i], log[2 * i + 1]) for i in range(k)], "saved": bool(saved.value)}
             self._result = (st, (self.ws, self.slots) if saved.value else None)
@@ -677,6 +690,7 @@ def odeint_dopri5_saving(stack, z0, t, rtol, atol, first_step=0.0, max_steps=0):
         out, st = odeint_dopri5(stack, z0, t, rtol, atol, first_step=first_step, max_steps=max_steps)
         st["saved"] = False
         return out, st, None
+    collect_pending_solves()
     require_device_tensor(z0, "y0")
     desc = stack.refresh()
     z0 = z0.contiguous()
@@ -786,6 +800,7 @@ def odeint_adjoint_backward(stack, method, t, y_traj, grad_out):
 def odeint_adjoint_dopri5_backward(stack, t, y_traj, grad_out, rtol, atol, max_accept=None, stats=None, mixed_norm=False):
     """torchdiffeq odeint_adjoint backward with method="dopri5" (seminorm, or the default mixed norm): (grad_z0, [grad_w...], [grad_b...]).
     `stats`, if a dict, receives nfe / n_accept / n_reject of the backward solve."""
+    collect_pending_solves()   # in particular the forward solve whose trajectory this integrates from (its error surfaces here)
     require_device_tensor(grad_out, "grad_out")
     require_device_tensor(y_traj, "y_traj")
     desc = stack.refresh()
@@ -1225,11 +1240,16 @@ class _FrameEncodeFn(torch.autograd.Function):
     def forward(ctx, seq, frames, w1, b1, w2, b2):
         out = frame_encode(seq, frames)
         ctx.seq = seq
+        ctx.params = (w1, b1, w2, b2)   # the backward re-packs from the live parameters: they must still be the forward's
+        ctx.versions = tuple(p._version for p in ctx.params)
         ctx.save_for_backward(frames, out, w2)
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("a parameter of the frame encoder was modified in place between forward and backward")
         frames, out, w2 = ctx.saved_tensors
         seq = ctx.seq
         c1, c2, slope = _codec_layers(seq, torch.nn.Conv2d, 3, 16)
@@ -1260,11 +1280,16 @@ class _FrameDecodeFn(torch.autograd.Function):
         else:
             pred, mid = frame_decode(seq, latents, apply_sigmoid), None
         ctx.seq, ctx.apply_sigmoid, ctx.has_mid = seq, bool(apply_sigmoid), mid is not None
+        ctx.params = (w1, b1, w2, b2)
+        ctx.versions = tuple(p._version for p in ctx.params)
         ctx.save_for_backward(latents, pred, w1, *([mid] if mid is not None else []))
         return pred
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("a parameter of the frame decoder was modified in place between forward and backward")
         latents, pred, w1 = ctx.saved_tensors[:3]
         mid = ctx.saved_tensors[3] if ctx.has_mid else None
         seq = ctx.seq

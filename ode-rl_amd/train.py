@@ -7,25 +7,41 @@ import pickle
 import torch
 
 
-def train_batch(model, batch_dict, optimizer, async_solver=True):
-    """One optimisation step.  async_solver: a dopri5 solve inside the model only enqueues its attempted steps and the backward
-    pass collects its outcome (ode_rl_amd.set_async_dopri5): the host goes on enqueueing decoder, loss and backward while the
-    device still integrates; a solver error (dt underflow, non-finite state) then surfaces at loss.backward().  batch_dict: 'observed_data' (B,T_in,C,H,W) and 'data_to_predict' (B,T_out,C,H,W) in
-    [-0.5, 0.5] as the reference's loaders deliver them, plus 'observed_tp' / 'tp_to_predict'.  Returns
-    (pred * 255, truth * 255, loss tensor, loss_dict) -- the loss stays on the device (no .item() synchronisation here)."""
+def train_batch(model, batch_dict, optimizer, async_solver=False):
+    """One optimisation step.  batch_dict: 'observed_data' (B,T_in,C,H,W) and 'data_to_predict' (B,T_out,C,H,W) in [-0.5, 0.5] as the
+    reference's loaders deliver them, plus 'observed_tp' / 'tp_to_predict'.  Returns (pred * 255, truth * 255, loss tensor, loss_dict)
+    -- the loss stays on the device (no .item() synchronisation here).
+
+    async_solver (opt-in): a dopri5 solve inside the model only enqueues its attempted steps and the backward pass collects its outcome
+    (ode_rl_amd.set_async_dopri5): the host goes on enqueueing decoder, loss and backward while the device still integrates.  A solver
+    error (dt underflow, non-finite state) then surfaces at loss.backward(), not inside the forward as in torchdiffeq.  A solve that
+    needs more attempted steps than were enqueued up front is SEALED on the device (its unreached frames are NaN, never stale memory)
+    and reported as AsyncSolveTruncated by the backward pass: nothing has touched the parameters at that point, so the step is
+    repeated here on the synchronous path (and the next asynchronous solve enqueues more attempts)."""
     dev = next(model.parameters()).device
     inp = batch_dict["observed_data"].to(dev) + 0.5          # train_test.py:180: [-0.5, 0.5] -> [0, 1]
     out = batch_dict["data_to_predict"].to(dev) + 0.5
-    from . import hip_ops
-    was = hip_ops.set_async_dopri5(True) if async_solver else hip_ops._async_dopri5
-    try:
+    from . import _lib, hip_ops
+
+    def step():
         optimizer.zero_grad()   # torch 2 default (set_to_none=True), as train_test.py:176 today: no fill + accumulate kernels per parameter
         pred = model.get_prediction(inp, batch_dict=batch_dict)
         loss = model.get_loss(pred, out)
         loss.backward()
-    finally:
-        if async_solver:
-            hip_ops.set_async_dopri5(was)
+        return pred, loss
+
+    if async_solver:
+        was = hip_ops.set_async_dopri5(True)
+        try:
+            try:
+                pred, loss = step()
+                hip_ops.collect_pending_solves()   # a solve nobody differentiated through (none in the models here) is checked too
+            finally:
+                hip_ops.set_async_dopri5(was)
+        except _lib.AsyncSolveTruncated:
+            pred, loss = step()
+    else:
+        pred, loss = step()
     optimizer.step()
     return pred.detach() * 255.0, out * 255.0, loss.detach(), {"Per Step Loss": loss.detach()}
 

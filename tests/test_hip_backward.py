@@ -417,12 +417,17 @@ def test_dopri5_saving_forward_equals_reintegration(cuda, first_step, batch):
 
 
 def test_async_dopri5_forward_matches_the_synchronous_one(cuda):
-    """Round 3: with ode_rl_amd.set_async_dopri5(True) a dopri5 solve only enqueues its attempted steps; the outcome is read at the
-    backward pass / at the first look into last_stats / at the next solve.  Same trajectory, same gradients (bit for bit), same
-    stats as the synchronous call -- also when the solve needs MORE attempts than were enqueued up front (forced rejections) --
-    and an error (max_num_steps) surfaces when the outcome is collected."""
+    """With ode_rl_amd.set_async_dopri5(True) a dopri5 solve only enqueues its attempted steps; the outcome is read at the backward
+    pass / at the first look into last_stats / at the next solve.  Same trajectory, same gradients (bit for bit), same stats as the
+    synchronous call, and an error (max_num_steps) surfaces when the outcome is collected.
+
+    Round 4: a solve that needs MORE attempts than were enqueued up front can no longer be completed behind its
+    consumers' backs.  It is sealed on the device -- what a consumer enqueued between forward and collect reads is NaN in the frames
+    the solve had not reached, never stale memory -- and collect() (here: backward) raises AsyncSolveTruncated, for odeint and for
+    odeint_adjoint alike; the next solve enqueues more attempts and matches the synchronous one again."""
     import ode_rl_amd
     from ode_rl_amd import hip_ops
+    from ode_rl_amd._lib import AsyncSolveTruncated
     f, _ = _setup(3)
     with torch.no_grad():
         f.gradient_net[8].weight.mul_(12.0)
@@ -432,7 +437,7 @@ def test_async_dopri5_forward_matches_the_synchronous_one(cuda):
     t = torch.tensor([0.0, 1.0, 2.5, 4.0], dtype=torch.float64)
     gout = torch.randn(4, 3, 64, 16, 16, generator=g).to(cuda)
 
-    def run(adjoint=False):
+    def forward(adjoint):
         f.zero_grad()
         z = z0.clone().requires_grad_(True)
         if adjoint:
@@ -440,34 +445,56 @@ def test_async_dopri5_forward_matches_the_synchronous_one(cuda):
                                             adjoint_options={"norm": "seminorm"})
         else:
             sol = ode_rl_amd.odeint(f, z, t, rtol=1e-4, atol=1e-5, method="dopri5", options={"first_step": 3.0})
+        return z, sol
+
+    def run(adjoint=False):
+        z, sol = forward(adjoint)
         sol.backward(gout)
         st = dict(ode_rl_amd.last_stats)
         return sol.detach().clone(), z.grad.clone(), [p.grad.clone() for p in f.parameters()], st
 
     ref = run()
     ref_adj = run(adjoint=True)
+    assert ref[3]["n_reject"] >= 2 and ref[3]["n_accept"] >= 3
     with torch.no_grad():
         ref_inf = ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5")
         ref_inf_stats = dict(ode_rl_amd.last_stats)
     was = ode_rl_amd.set_async_dopri5(True)
     attempts = hip_ops._async_attempts
     try:
-        hip_ops._async_attempts = 2          # fewer than the solve needs (2 rejected + 3 accepted): collect() must carry on
-        got = run()
-        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
-        for k in ("nfe", "n_accept", "n_reject", "accepted"):
-            assert got[3][k] == ref[3][k], k
-        assert ref[3]["n_reject"] >= 2 and ref[3]["n_accept"] >= 3
-        assert hip_ops._async_attempts >= 5  # the next solve enqueues what this one needed
-        got2 = run()                         # ... and then needs no second round
-        assert torch.equal(got2[1], ref[1])
-        gadj = run(adjoint=True)
-        assert torch.equal(gadj[0], ref_adj[0]) and torch.equal(gadj[1], ref_adj[1])
+        for adjoint in (False, True):
+            hip_ops._async_attempts = 2      # fewer than the solve needs (2 rejected + 3 accepted)
+            z, sol = forward(adjoint)
+            # a CONSUMER between the forward and the collect (the decoder and the loss of a training step): it must not see
+            # uninitialised frames.  Frame 0 (= z0) is there, the last frame cannot have been reached by two attempts: NaN
+            seen = sol.detach().clone()
+            assert len(hip_ops._pending_solves) == 1
+            with pytest.raises(AsyncSolveTruncated):
+                sol.backward(gout)
+            assert not hip_ops._pending_solves
+            assert torch.equal(seen[0], z0) and bool(torch.isnan(seen[-1]).all())
+            assert bool((torch.isnan(seen).flatten(1).all(1) | torch.isfinite(seen).flatten(1).all(1)).all())   # whole frames only
+            assert hip_ops._async_attempts >= 4          # the next solve enqueues more ...
+            with pytest.raises(AsyncSolveTruncated):     # ... 4 is still short of 5: sealed again, never silently completed
+                run(adjoint)
+            assert hip_ops._async_attempts >= 8
+            got = run(adjoint)                           # ... and now the solve fits: bit-identical to the synchronous call
+            want = ref_adj if adjoint else ref
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and all(torch.equal(a, b) for a, b in zip(got[2], want[2]))
+            for k in ("nfe", "n_accept", "n_reject", "accepted"):
+                assert got[3][k] == want[3][k], k
         with torch.no_grad():
             inf = ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5")
             assert len(hip_ops._pending_solves) == 1          # nothing has been waited for yet
             assert ode_rl_amd.last_stats["nfe"] == ref_inf_stats["nfe"] and not hip_ops._pending_solves
         assert torch.equal(inf, ref_inf)
+        # a synchronous entry point first collects what is in flight (it shares the solver workspace with it)
+        with torch.no_grad():
+            inf = ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5")
+            assert len(hip_ops._pending_solves) == 1
+            from ode_rl_amd.odeint import conv_stack_of
+            sync_out, _ = hip_ops.odeint_dopri5(conv_stack_of(f), z0, hip_ops.host_times(t), 1e-4, 1e-5)
+            assert not hip_ops._pending_solves and torch.equal(sync_out, ref_inf) and torch.equal(inf, ref_inf)
         # an error is reported when the outcome is collected, as the exception the synchronous call raises
         with torch.no_grad():
             ode_rl_amd.odeint(f, z0, t, rtol=1e-4, atol=1e-5, method="dopri5", options={"first_step": 3.0, "max_num_steps": 2})
