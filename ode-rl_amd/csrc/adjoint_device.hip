@@ -314,7 +314,9 @@ int adjoint_dopri5_device(const odehip_convstack* f, const odehip_convstack* f_d
                           float* const* grad_b, int max_accept, int* stats_host, void* workspace, size_t workspace_bytes, hipStream_t stream,
                           int* ran) {
   *ran = 0;
-  static const bool env_off = [] { const char* e = getenv("ODEHIP_ADJOINT_DEVICE"); return e && e[0] == '0'; }();
+  // read per call (not cached): the parity tests run the host-driven loop and this one in ONE process on the same inputs
+  const char* const env_e = getenv("ODEHIP_ADJOINT_DEVICE");
+  const bool env_off = env_e && env_e[0] == '0';
   if (env_off || !all_64(f) || n_times < 2 || n_times > kAdjMaxTimes || g_debug_flags) return ODEHIP_OK;
   const AdjLayout L(f, batch, n_times, max_accept);
   ODEHIP_REQUIRE(workspace_bytes >= L.total, "odeint_adjoint_dopri5_backward: workspace too small");

@@ -20,7 +20,12 @@ run config0_b4 --batch 4 --no-config0 --no-cpu-baseline --no-model
 run config1_train --train --no-cpu-baseline --no-model
 run dopri5_fwd --method dopri5 --no-cpu-baseline --no-config0 --no-model
 run dopri5_train --method dopri5 --train --no-cpu-baseline --no-model
-run config2_adjoint --method dopri5 --train --adjoint --rtol 1e-5 --atol 1e-6 --no-cpu-baseline --steps 20 --no-model
+# configs[2]: rtol 1e-5 as BASELINE.json states; atol is unstated there = the reference's DiffEqSolver default 1e-5.
+# Both adjoint norms: the seminorm, and torchdiffeq's default MIXED norm (every parameter tensor's error ratio steers the steps: an
+# order of magnitude more backward steps by construction, in torchdiffeq as here)
+run config2_adjoint --method dopri5 --train --adjoint --rtol 1e-5 --no-cpu-baseline --steps 20 --no-model
+run config2_adjoint_mixed --method dopri5 --train --adjoint --adjoint-norm mixed --rtol 1e-5 --no-cpu-baseline --steps 3 --warmup 1 --no-model --no-config0
+run config2_adjoint_atol1e-6 --method dopri5 --train --adjoint --rtol 1e-5 --atol 1e-6 --no-cpu-baseline --steps 20 --no-model --no-config0
 run config3_vidode_fwd --shape V --no-cpu-baseline --no-config0 --no-model
 run config3_vidode_train --shape V --train --no-cpu-baseline --no-model
 run config4_bf16_fwd --dtype bf16 --batch 128 --frames 40 --no-cpu-baseline --no-config0 --steps 20 --no-model
