@@ -193,12 +193,14 @@ def test_max_num_steps_counts_per_output_time(cuda):
 
 
 @pytest.mark.parametrize("method", ["rk4", "midpoint", "euler"])
-@pytest.mark.parametrize("batch", [1, 3, 4, 8, 9, 16])
+@pytest.mark.parametrize("batch", [1, 3, 4, 8, 9, 16, 17, 31, 32, 33, 47, 64, 65, 100])
 def test_small_batch_walk_is_bit_identical_to_one_launch_per_layer(cuda, method, batch):
     """Round 3: batches up to 16 (the reference trains at 4, configs.yaml:7) walk a forward trajectory with SIXTEEN workgroups per
     sample (wino_persist16_kernel: the transform positions of a block split over the consumer waves, the output transform finished
     through LDS in the 4-workgroup kernel's order of operations).  Bit-identical to one launch per layer, for every slot of the
-    sample -> XCD mapping (1 .. 16 samples), with and without result frames in the last stage; B = 17 takes the other walk."""
+    sample -> XCD mapping (1 .. 16 samples), with and without result frames in the last stage.  Round 4: batches 17 .. 64 take the
+    EIGHT-workgroup walk (wino_persist8_kernel: 32 groups of eight; one sample per group up to 32, two interleaved above -- 33 and 47
+    mix both), 65 and 100 the four-workgroup walk again: every one of them bit-identical to one launch per layer."""
     import ode_rl_amd
     if not _persistent_on():
         pytest.skip("persistent path switched off for this run")
