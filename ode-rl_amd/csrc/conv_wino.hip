@@ -1034,23 +1034,14 @@ int launch_wino_persist_small(const ConvArgs* items, int n_layers, int batch, un
 // 64 words (16 workgroups x 4 consumer waves); a workgroup waits for the twelve workgroups of row quarters rq-1 .. rq+1 (all channels
 // of the input rows it reads).  Forward tables (plain / ReLU stores, the prefetched stage combine) and reverse sweeps (mask layers
 // prefetched, targets through the shared epilogue); LDS 88 KiB.
-// NB = 16-channel blocks per workgroup.  NB = 1: the sixteen-workgroup walk above.  NB = 2 (round 4): EIGHT workgroups per sample --
-// workgroup (sample, 32-channel tile ct, row quarter rq), the consumer waves still split the positions by column and each holds the
-// column's four positions for BOTH channel blocks (32 MFMAs per 16-channel chunk and wave, 12 fragment reads).  It exists for batches
-// of 17 .. 64: a group of eight workgroups (one XCD) walks TWO samples, layer by layer in turn, so that the hand-off of one sample's
-// layer (stores acknowledged -> flags -> input tile -> first transform: ~2.2 us, which the four-workgroup walk pays on every 7.3 us
-// layer at one sample per group) is covered by the other sample's layer -- at the configs' own batch of 64, where the four-workgroup
-// walk has nothing to interleave.  Same order of operations per output value as the other walks: bit-identical results.
+constexpr int k16U = 16 * 1024;    // U chunk: 16 xi x [quad 4][co 16][4 ci]
 constexpr int k16Raw = 8 * 1024;   // raw chunk: 4 quads x 2 KiB: 6 rows x 20 slots of 16 B
 constexpr int k16V = 16 * 1024;    // V chunk: 16 xi x [quad 4][tile 16][4 ci]
-template <int NB> struct W16 {
-  static constexpr int kU = NB * 16 * 1024;   // U chunk: 16 xi x [quad 4][co 16 NB][4 ci]
-  static constexpr int kX = NB * 8 * 1024;    // exchange: [block NB][a 2][col 4][lane 64] quads
-  static constexpr int kLds = 2 * kU + 2 * k16Raw + 2 * k16V + kX;
-  static constexpr int kWordsPerRq = 16 / NB; // flag words of a row quarter: (4 / NB channel tiles) x 4 consumer waves
-  static constexpr int kNU = 4 * NB;          // U DMA instructions per producer wave and chunk
-};
-constexpr int kWino16Lds = W16<1>::kLds;
+constexpr int k16X = 8 * 1024;     // exchange: [a 2][col 4][lane 64] quads
+constexpr int kWino16Lds = 2 * k16U + 2 * k16Raw + 2 * k16V + k16X;
+// URES (round 4, wino_persist16x_kernel): the layer's WHOLE U for this 16-channel tile stays in LDS (4 chunks, 64 KiB) while the group
+// walks up to four samples through the layer
+constexpr int kWino16xLds = 4 * k16U + 2 * k16Raw + 2 * k16V + k16X;   // 120 KiB
 
 struct Hook16 {
   unsigned* done;      // the sample's 64 flag words
@@ -1062,7 +1053,10 @@ struct Hook16 {
   int sleep6;
   const unsigned long long* reloc;   // relocation bases of an adaptive table (rel()), or null
   unsigned wait_target;              // target, or target - 1 for a row that does not depend on the row in front of it (dep_back)
-  bool solo;                         // one sample per group: the producers sleep in front of their first poll
+  // URES only:
+  bool solo;                         // the group walks one sample: the producers sleep in front of their first poll
+  bool load_u;                       // this layer's U is not in LDS yet (the first sample of a round when nothing was prefetched)
+  const float* u_next;               // the last sample of a round: the next conv row's U, loaded into the chunk buffers as they fall free
 };
 
 __device__ __forceinline__ void wait_done16(const Hook16& hk, int lo_word, int hi_word) {
@@ -1083,15 +1077,14 @@ __device__ __forceinline__ void wait_done16(const Hook16& hk, int lo_word, int h
   if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// cq: the workgroup's channel tile of 16 NB channels (NB = 1: 0 .. 3; NB = 2: 0 .. 1 = the 32-channel tile ct)
-template <int NB>
+template <bool URES>
 __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, const float* __restrict__ p_u, const ConvArgs& a, int b,
                                              int cq, int rq, char* smem, const Hook16& hk) {
-  typedef W16<NB> W;
+  constexpr int kNUB = URES ? 4 : 2;   // U chunk buffers
   char* const Ub = smem;
-  char* const Rb = smem + 2 * W::kU;
-  char* const Vb = smem + 2 * W::kU + 2 * k16Raw;
-  char* const Xb = smem + 2 * W::kU + 2 * k16Raw + 2 * k16V;
+  char* const Rb = smem + kNUB * k16U;
+  char* const Vb = smem + kNUB * k16U + 2 * k16Raw;
+  char* const Xb = smem + kNUB * k16U + 2 * k16Raw + 2 * k16V;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1101,8 +1094,8 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
   if (wave >= 4) {
     // =========================================== PRODUCERS ===========================================
     const int pw = wave - 4;
-    const int ct = NB == 1 ? cq >> 1 : cq, half = cq & 1;
-    const unsigned u_tile_bytes = (unsigned)nchunk * kWU;   // the 32-channel tile (NB = 1: the one this 16-channel tile is half of)
+    const int ct = cq >> 1, half = cq & 1;
+    const unsigned u_tile_bytes = (unsigned)nchunk * kWU;   // the 32-channel tile this 16-channel tile is half of
     const __amdgpu_buffer_rsrc_t ru = make_rsrc((const char*)p_u + (size_t)ct * u_tile_bytes, u_tile_bytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)p_src + (size_t)b * 16 * kQuadBytes, 16u * kQuadBytes);
     int vr[2];
@@ -1114,17 +1107,16 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
       const int irow = r0 - 1 + row, col = pc - 1;
       vr[p] = (s < 120 && w < 18 && irow >= 0 && irow < kHW && col >= 0 && col < kHW) ? irow * 256 + col * 16 : kOobOffset;
     }
-    // U, NB = 1: the chunk's 64 (xi, quad) pieces of this channel half are 256 B each, 512 B apart: one instruction moves four of them
-    // NB = 2: the 32-channel chunk as it lies (1 KiB per instruction)
-    const int vu = NB == 1 ? (lane >> 4) * 512 + half * 256 + (lane & 15) * 16 : lane * 16;
-    auto issue_u = [&](int c, int buf) {
+    // U: the chunk's 64 (xi, quad) pieces of this channel half are 256 B each, 512 B apart: one instruction moves four of them
+    const int vu = (lane >> 4) * 512 + half * 256 + (lane & 15) * 16;
+    auto issue_u_from = [&](const __amdgpu_buffer_rsrc_t& r, int c, int buf) {
 #pragma unroll
-      for (int g = 0; g < W::kNU; ++g) {
-        const int p = pw * W::kNU + g;
-        if (NB == 1) dma16(ru, Ub + buf * W::kU + p * 1024, vu, c * kWU + p * 2048);   // pieces 4p .. 4p + 3
-        else         dma16(ru, Ub + buf * W::kU + p * 1024, vu, c * kWU + p * 1024);
+      for (int g = 0; g < 4; ++g) {
+        const int p = pw * 4 + g;   // pieces 4p .. 4p + 3
+        dma16(r, Ub + buf * k16U + p * 1024, vu, c * kWU + p * 2048);
       }
     };
+    auto issue_u = [&](int c, int buf) { issue_u_from(ru, c, buf); };
     auto issue_raw = [&](int c, int buf) {
 #pragma unroll
       for (int p = 0; p < 2; ++p)
@@ -1157,12 +1149,52 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
       *(f32x4*)(v + 2 * 1024) = pk_sub(T[2], T[1]);
       *(f32x4*)(v + 3 * 1024) = pk_sub(T[1], T[3]);
     };
-    // DMA order per wave: U_0 (kNU) | raw_0 (2) | raw_1 (2) | then per iteration c: U_{c+1} (kNU) | raw_{c+2} (2)
+    if constexpr (URES) {
+      // U is RESIDENT: chunk c of the layer's U lives in buffer c for the whole round (up to four samples).  load_u: nothing was
+      // prefetched (first row of a walk, or the row before did not know this one): all four chunks are requested now.  u_next (the last
+      // sample of the round): the next conv row's chunks go into the buffers as this layer's consumers leave them -- chunk c - 1 behind
+      // barrier [c], chunk 3 behind the exchange barrier -- so the next round starts with its weights in place.
+      // DMA order per wave: [U_0..U_3 (16)] | raw_0 (2) | raw_1 (2) | per iteration c: [U'_{c-1} (4)] | raw_{c+2} (2) | ... | [U'_2] | [U'_3]
+      const bool pf = hk.u_next != nullptr;
+      const __amdgpu_buffer_rsrc_t run = make_rsrc((const char*)(pf ? hk.u_next : p_u) + (size_t)ct * u_tile_bytes, u_tile_bytes);
+      if (hk.load_u) {
+#pragma unroll
+        for (int c = 0; c < nchunk; ++c) issue_u(c, c);
+      }
+      if (!hk.first) {
+        if (hk.solo && hk.wait_target == hk.target)
+          for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
+        const int lo = rq > 0 ? (rq - 1) * 16 : 0, hi = rq < 3 ? (rq + 2) * 16 : 64;
+        wait_done16(hk, lo, hi);
+      }
+      issue_raw(0, 0);
+      issue_raw(1, 1);
+      wait_vmcnt<2>();   // raw_0 landed, and with it every older request: this layer's U (loaded now or prefetched by the last round)
+      transform(0, 0);
+#pragma unroll
+      for (int c = 0; c < nchunk; ++c) {
+        __builtin_amdgcn_s_barrier();  // [c]
+        if (pf && c >= 1) issue_u_from(run, c - 1, c - 1);   // buffer c - 1: the consumers are through chunk c - 1
+        if (c + 1 < nchunk) {
+          if (c + 2 < nchunk) {
+            issue_raw(c + 2, c & 1);
+            if (pf && c >= 1) wait_vmcnt<6>(); else wait_vmcnt<2>();   // raw_{c+1} landed (younger: [U'_{c-1}], raw_{c+2})
+          } else {
+            if (pf) wait_vmcnt<4>(); else wait_vmcnt<0>();   // raw_3 landed (younger: U'_1)
+          }
+          transform((c + 1) & 1, (c + 1) & 1);
+        }
+      }
+      __builtin_amdgcn_s_barrier();    // [X] the consumers' exchange
+      if (pf) issue_u_from(run, 3, 3);
+      return;
+    }
+    // DMA order per wave: U_0 (4) | raw_0 (2) | raw_1 (2) | then per iteration c: U_{c+1} (4) | raw_{c+2} (2)
     issue_u(0, 0);
     if (!hk.first) {
-      if (hk.solo && hk.wait_target == hk.target)   // (a row with a relaxed dependency has nothing to sleep for)
+      if (hk.wait_target == hk.target)   // (a row with a relaxed dependency has nothing to sleep for)
         for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
-      const int lo = rq > 0 ? (rq - 1) * W::kWordsPerRq : 0, hi = rq < 3 ? (rq + 2) * W::kWordsPerRq : 4 * W::kWordsPerRq;
+      const int lo = rq > 0 ? (rq - 1) * 16 : 0, hi = rq < 3 ? (rq + 2) * 16 : 64;
       wait_done16(hk, lo, hi);
     }
     issue_raw(0, 0);
@@ -1176,9 +1208,9 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
         issue_u(c + 1, (c + 1) & 1);
         if (c + 2 < nchunk) {
           issue_raw(c + 2, c & 1);
-          wait_vmcnt<W::kNU + 2>();  // raw_{c+1} landed
+          wait_vmcnt<6>();           // raw_{c+1} landed
         } else {
-          wait_vmcnt<W::kNU>();
+          wait_vmcnt<4>();
         }
         transform((c + 1) & 1, (c + 1) & 1);
         if (c + 2 < nchunk) wait_vmcnt<2>(); else wait_vmcnt<0>();  // U_{c+1} landed
@@ -1190,38 +1222,29 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
 
   // ============================================= CONSUMERS =============================================
   const int i16 = lane & 15, kq = lane >> 4;
-  f32x4 acc[NB][4];
+  f32x4 acc[4];
 #pragma unroll
-  for (int k = 0; k < NB; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int v_frag = kq * 256 + i16 * 16;                  // offset in a V position block
-  const int u_frag = kq * (256 * NB) + i16 * 16;           // offset in a U position block (+ k * 256: channel block k)
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_off = kq * 256 + i16 * 16;       // same offset in a U and in a V position block
+  const int Q = cq * 4 + kq;
   const int oa = wave >> 1, ob = wave & 1;        // the output pixel of every 2x2 tile this wave finishes
   const int oty = i16 >> 3, otx = i16 & 7;
   const int P = (r0 + 2 * oty + oa) * 16 + 2 * otx + ob;
-  int Q[NB];
-  size_t off[NB];
-  f32x4 bias4[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    Q[k] = (cq * NB + k) * 4 + kq;
-    off[k] = (((size_t)b * 16 + Q[k]) * kPix + P) * 4;
-    bias4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.bias) bias4[k] = *(const f32x4*)(a.bias + Q[k] * 4);
-  }
+  const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *(const f32x4*)(a.bias + Q * 4);
   // epilogue operands fetched now (this lane's own earlier outputs, as in the 4-workgroup walk)
   const unsigned long long* const rl = hk.reloc;
   typedef const __attribute__((address_space(4))) float ConstF16;
   // an order-1 stage combine (the adaptive solver's tables) is reduced to y, two partial sums and y1 here, a reverse-sweep row with
   // up to two constant-coefficient targets to its (srcA, srcB) pairs -- the adaptive walk's scheme (wino_layer<..., ADAPT>), one quad
-  // per lane and channel block; pointers may be relocatable
+  // per lane; pointers may be relocatable
   const bool adapt1 = a.combine == 1 && a.cmb.order == 1 && !(a.cmb.err_partials && (a.cmb.out2 || a.dbg));
   const bool adapt3 = a.combine == 3 && a.bwd.n_targets <= 2 && !a.bwd.h_ptr;
   const int e_combine = adapt1 ? 6 : (adapt3 ? 7 : a.combine);
   const int e_relu = a.relu;
   float* const e_dst = rel(rl, a.dst);
-  f32x4 d_y1[NB], d_sa[NB], d_sb[NB];
+  f32x4 d_y1 = {0.f, 0.f, 0.f, 0.f}, d_sa = {0.f, 0.f, 0.f, 0.f}, d_sb = {0.f, 0.f, 0.f, 0.f};
   float d_cB = 0.0f, d_rtol = 0.0f, d_atol = 0.0f, d_t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float* d_o[2] = {nullptr, nullptr};
   bool d_err = false, d_f[4] = {false, false, false, false};
@@ -1233,9 +1256,7 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
   float* e_nchw = nullptr;
   bool e_y = false;
   float e_h = 1.0f, e_ks = 1.0f, e_c1c = 0.0f, e_c2c = 0.0f, e_c1[3] = {0.f, 0.f, 0.f}, e_c2[3] = {0.f, 0.f, 0.f};
-  f32x4 e_yv[NB], e_kv[3][NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) d_y1[k] = d_sa[k] = d_sb[k] = e_yv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 e_yv = {0.f, 0.f, 0.f, 0.f}, e_kv[3];
   if (e_combine == 1) {
     const CombineArgs& m = a.cmb;
     e_np = m.n_prev;
@@ -1250,15 +1271,10 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
     e_out2 = m.out2;
     e_nchw = a.dbg ? hk.nchw_base + ((size_t)a.dbg - 1) : nullptr;
     e_y = m.y != nullptr;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      if (e_y) e_yv[k] = *(const f32x4*)(m.y + off[k]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j < e_np) e_kv[j][k] = *(const f32x4*)(m.k_prev[j] + off[k]);
-    }
+    if (e_y) e_yv = *(const f32x4*)(m.y + off);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+      if (j < e_np) e_kv[j] = *(const f32x4*)(m.k_prev[j] + off);
       e_c1[j] = m.c1[j];
       e_c2[j] = m.c2[j];
     }
@@ -1267,11 +1283,7 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
     const float hb = a.h_by_value ? a.cmb.atol : (w.h_ptr ? *(ConstF16*)w.h_ptr : 0.0f);
     e_ks = w.sc_c + w.sc_h * hb;
     e_y = w.mask_src != nullptr;
-    if (e_y) {
-      const float* const mk = rel(rl, w.mask_src);
-#pragma unroll
-      for (int k = 0; k < NB; ++k) e_yv[k] = *(const f32x4*)(mk + off[k]);
-    }
+    if (e_y) e_yv = *(const f32x4*)(rel(rl, w.mask_src) + off);
   } else if (e_combine == 6) {   // order-1 stage combine: the sums over the earlier stages (combine1_prev's fma sequence)
     const CombineArgs& m = a.cmb;
     e_np = m.n_prev;
@@ -1289,13 +1301,8 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
     e_nchw = m.out2_nchw;
     const bool needB = d_err || e_out2 || e_nchw;
     if (e_y) {
-      const float* const yp = rel(rl, m.y);
-      const float* const y1p = d_err ? rel(rl, m.err_y1) : nullptr;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        e_yv[k] = *(const f32x4*)(yp + off[k]);
-        if (d_err) d_y1[k] = *(const f32x4*)(y1p + off[k]);
-      }
+      e_yv = *(const f32x4*)(rel(rl, m.y) + off);
+      if (d_err) d_y1 = *(const f32x4*)(rel(rl, m.err_y1) + off);
       const float* kp[ODEHIP_MAX_STAGES - 1];
       float cA[ODEHIP_MAX_STAGES - 1], cB[ODEHIP_MAX_STAGES - 1];
 #pragma unroll
@@ -1307,12 +1314,9 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
 #pragma unroll
       for (int j = 0; j < ODEHIP_MAX_STAGES - 1; ++j)
         if (j < e_np) {
-#pragma unroll
-          for (int k = 0; k < NB; ++k) {
-            const f32x4 kv = *(const f32x4*)(kp[j] + off[k]);
-            d_sa[k] = fma4(kv, cA[j], d_sa[k]);
-            if (needB) d_sb[k] = fma4(kv, cB[j], d_sb[k]);
-          }
+          const f32x4 kv = *(const f32x4*)(kp[j] + off);
+          d_sa = fma4(kv, cA[j], d_sa);
+          if (needB) d_sb = fma4(kv, cB[j], d_sb);
         }
     }
   } else if (e_combine == 7) {   // reverse-sweep targets held in registers
@@ -1324,159 +1328,135 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
         d_o[t] = rel(rl, T.out);
         d_t[3 * t] = T.g_c; d_t[3 * t + 1] = T.a_c; d_t[3 * t + 2] = T.b_c;
         d_f[2 * t] = T.srcA != nullptr; d_f[2 * t + 1] = T.srcB != nullptr;
-        const float* const sA = rel(rl, T.srcA);
-        const float* const sB = rel(rl, T.srcB);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          if (t == 0) {
-            if (d_f[0]) e_yv[k] = *(const f32x4*)(sA + off[k]);
-            if (d_f[1]) d_y1[k] = *(const f32x4*)(sB + off[k]);
-          } else {
-            if (d_f[2]) d_sa[k] = *(const f32x4*)(sA + off[k]);
-            if (d_f[3]) d_sb[k] = *(const f32x4*)(sB + off[k]);
-          }
+        if (t == 0) {
+          if (d_f[0]) e_yv = *(const f32x4*)(rel(rl, T.srcA) + off);
+          if (d_f[1]) d_y1 = *(const f32x4*)(rel(rl, T.srcB) + off);
+        } else {
+          if (d_f[2]) d_sa = *(const f32x4*)(rel(rl, T.srcA) + off);
+          if (d_f[3]) d_sb = *(const f32x4*)(rel(rl, T.srcB) + off);
         }
       }
   }
 #pragma unroll
   for (int c = 0; c < nchunk; ++c) {
     __builtin_amdgcn_s_barrier();  // [c]
-    const char* u = Ub + (c & 1) * W::kU + u_frag;
-    const char* v = Vb + (c & 1) * k16V + v_frag;
-    f32x4 wf[NB][4], xf[4];
+    const char* u = Ub + (URES ? c : (c & 1)) * k16U + frag_off;
+    const char* v = Vb + (c & 1) * k16V + frag_off;
+    f32x4 wf[4], xf[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      wf[i] = *(const f32x4*)(u + (4 * i + wave) * 1024);
       xf[i] = *(const f32x4*)(v + (4 * i + wave) * 1024);
-#pragma unroll
-      for (int k = 0; k < NB; ++k) wf[k][i] = *(const f32x4*)(u + (4 * i + wave) * (1024 * NB) + k * 256);
     }
-    // per position the chunk's four K-steps in the 4-workgroup kernel's order (.x .y .z .w); the positions (and blocks) interleaved
+    // per position the chunk's four K-steps in the 4-workgroup kernel's order (.x .y .z .w); the four positions interleaved
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].x, xf[i].x, acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][i].x, xf[i].x, acc[k][i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].y, xf[i].y, acc[i], 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].z, xf[i].z, acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][i].y, xf[i].y, acc[k][i], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][i].z, xf[i].z, acc[k][i], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[k][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[k][i].w, xf[i].w, acc[k][i], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i].w, xf[i].w, acc[i], 0, 0, 0);
   }
   // first half of the output transform, over the rows of M (this wave's column): the 4-workgroup kernel's S[0][col], S[1][col]
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const f32x4 S0 = acc[k][0] + acc[k][1] + acc[k][2];
-    const f32x4 S1 = pk_sub(pk_sub(acc[k][1], acc[k][2]), acc[k][3]);
-    *(f32x4*)(Xb + k * 8192 + (0 * 4 + wave) * 1024 + lane * 16) = S0;
-    *(f32x4*)(Xb + k * 8192 + (1 * 4 + wave) * 1024 + lane * 16) = S1;
+  {
+    const f32x4 S0 = acc[0] + acc[1] + acc[2];
+    const f32x4 S1 = pk_sub(pk_sub(acc[1], acc[2]), acc[3]);
+    *(f32x4*)(Xb + (0 * 4 + wave) * 1024 + lane * 16) = S0;
+    *(f32x4*)(Xb + (1 * 4 + wave) * 1024 + lane * 16) = S1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();    // [X]
-  float esum_all = 0.0f;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    f32x4 val;
-    {
-      const char* x = Xb + k * 8192 + oa * 4 * 1024 + lane * 16;
-      if (ob == 0) {
-        val = *(const f32x4*)(x) + *(const f32x4*)(x + 1024) + *(const f32x4*)(x + 2048) + bias4[k];
-      } else {
-        val = pk_sub(pk_sub(*(const f32x4*)(x + 1024) + bias4[k], *(const f32x4*)(x + 2048)), *(const f32x4*)(x + 3072));
-      }
-    }
-    const size_t o4 = off[k];
-    if (!e_combine) {
-      if (e_relu) {
-        val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
-      }
-      *(f32x4*)(e_dst + o4) = val;
-    } else if (e_combine == 2) {
-      val *= e_ks;
-      if (e_y) {
-        val.x = e_yv[k].x > 0.0f ? val.x : 0.0f; val.y = e_yv[k].y > 0.0f ? val.y : 0.0f;
-        val.z = e_yv[k].z > 0.0f ? val.z : 0.0f; val.w = e_yv[k].w > 0.0f ? val.w : 0.0f;
-      }
-      *(f32x4*)(e_dst + o4) = val;
-    } else if (e_combine == 3) {   // reverse-sweep targets: the shared epilogue, read from the table
-      float esum = 0.0f;
-      emit_quad<false>(a, b, Q[k], P, val, esum);
-    } else if (e_combine == 6) {
-      const f32x4 kc = val * e_ks;
-      if (e_kout) *(f32x4*)(e_kout + o4) = kc;
-      if (e_y) {
-        if (e_out1) *(f32x4*)(e_out1 + o4) = fma4(fma4(kc, e_c1c, d_sa[k]), e_h, e_yv[k]);
-        if (d_err) {
-          esum_all = combine1_err(fma4(kc, d_cB, d_sb[k]), e_h, e_yv[k], d_y1[k], d_rtol, d_atol, esum_all);
-        } else if (e_out2 || e_nchw) {
-          const f32x4 o2 = fma4(fma4(kc, d_cB, d_sb[k]), e_h, e_yv[k]);
-          if (e_out2) *(f32x4*)(e_out2 + o4) = o2;
-          if (e_nchw) {
-            float* o = e_nchw + ((size_t)b * 64 + Q[k] * 4) * kPix + P;
-            o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
-          }
-        }
-      }
-    } else if (e_combine == 7) {
-      if (d_o[0]) {
-        f32x4 o = val * d_t[0];
-        if (d_f[0]) o = fma4(e_yv[k], d_t[1], o);
-        if (d_f[1]) o = fma4(d_y1[k], d_t[2], o);
-        *(f32x4*)(d_o[0] + o4) = o;
-      }
-      if (d_o[1]) {
-        f32x4 o = val * d_t[3];
-        if (d_f[2]) o = fma4(d_sa[k], d_t[4], o);
-        if (d_f[3]) o = fma4(d_sb[k], d_t[5], o);
-        *(f32x4*)(d_o[1] + o4) = o;
-      }
+  f32x4 val;
+  {
+    const char* x = Xb + oa * 4 * 1024 + lane * 16;
+    if (ob == 0) {
+      val = *(const f32x4*)(x) + *(const f32x4*)(x + 1024) + *(const f32x4*)(x + 2048) + bias4;
     } else {
-      const f32x4 kc = val * e_ks;
-      if (e_kout) *(f32x4*)(e_kout + o4) = kc;
-      if (e_y) {
-        if (e_out1) {
-          f32x4 sa = kc * e_c1c;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            if (j < e_np) sa += e_kv[j][k] * e_c1[j];
-          *(f32x4*)(e_out1 + o4) = e_yv[k] + sa * e_h;
-        }
-        if (e_out2 || e_nchw) {
-          f32x4 sb = kc * e_c2c;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            if (j < e_np) sb += e_kv[j][k] * e_c2[j];
-          const f32x4 o2 = e_yv[k] + sb * e_h;
-          if (e_out2) *(f32x4*)(e_out2 + o4) = o2;
-          if (e_nchw) {
-            float* o = e_nchw + ((size_t)b * 64 + Q[k] * 4) * kPix + P;
-            o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
-          }
-        }
-      }
+      val = pk_sub(pk_sub(*(const f32x4*)(x + 1024) + bias4, *(const f32x4*)(x + 2048)), *(const f32x4*)(x + 3072));
     }
   }
-  if (e_combine == 6 && e_y && d_err) {
-    // this wave's partial of the error norm: 64 / NB partials per sample here (16 / NB workgroups x 4 waves), added by the controller
-    // in a fixed order -- not the per-layer kernels' order, so these batches agree with one launch per layer to round-off of the
-    // NORM only (every stored value is still bit-identical)
-    float esum = esum_all;
+  if (!e_combine) {
+    if (e_relu) {
+      val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
+    }
+    *(f32x4*)(e_dst + off) = val;
+  } else if (e_combine == 2) {
+    val *= e_ks;
+    if (e_y) {
+      val.x = e_yv.x > 0.0f ? val.x : 0.0f; val.y = e_yv.y > 0.0f ? val.y : 0.0f;
+      val.z = e_yv.z > 0.0f ? val.z : 0.0f; val.w = e_yv.w > 0.0f ? val.w : 0.0f;
+    }
+    *(f32x4*)(e_dst + off) = val;
+  } else if (e_combine == 3) {   // reverse-sweep targets: the shared epilogue, read from the table
+    float esum = 0.0f;
+    emit_quad<false>(a, b, Q, P, val, esum);
+  } else if (e_combine == 6) {
+    const f32x4 kc = val * e_ks;
+    if (e_kout) *(f32x4*)(e_kout + off) = kc;
+    if (e_y) {
+      if (e_out1) *(f32x4*)(e_out1 + off) = fma4(fma4(kc, e_c1c, d_sa), e_h, e_yv);
+      if (d_err) {
+        // this wave's partial of the error norm: 64 partials per sample here (16 workgroups x 4 waves), added by the controller in a
+        // fixed order -- not the per-layer kernels' order, so batches up to 16 agree with one launch per layer to round-off of the
+        // NORM only (every stored value is still bit-identical)
+        float esum = combine1_err(fma4(kc, d_cB, d_sb), e_h, e_yv, d_y1, d_rtol, d_atol, 0.0f);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-    if (lane == 0) d_part[((b * 4 + rq) * (4 / NB) + cq) * 4 + wave] = esum;
+        for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+        if (lane == 0) d_part[(b * 16 + rq * 4 + cq) * 4 + wave] = esum;
+      } else if (e_out2 || e_nchw) {
+        const f32x4 o2 = fma4(fma4(kc, d_cB, d_sb), e_h, e_yv);
+        if (e_out2) *(f32x4*)(e_out2 + off) = o2;
+        if (e_nchw) {
+          float* o = e_nchw + ((size_t)b * 64 + Q * 4) * kPix + P;
+          o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+        }
+      }
+    }
+  } else if (e_combine == 7) {
+    if (d_o[0]) {
+      f32x4 o = val * d_t[0];
+      if (d_f[0]) o = fma4(e_yv, d_t[1], o);
+      if (d_f[1]) o = fma4(d_y1, d_t[2], o);
+      *(f32x4*)(d_o[0] + off) = o;
+    }
+    if (d_o[1]) {
+      f32x4 o = val * d_t[3];
+      if (d_f[2]) o = fma4(d_sa, d_t[4], o);
+      if (d_f[3]) o = fma4(d_sb, d_t[5], o);
+      *(f32x4*)(d_o[1] + off) = o;
+    }
+  } else {
+    const f32x4 kc = val * e_ks;
+    if (e_kout) *(f32x4*)(e_kout + off) = kc;
+    if (e_y) {
+      if (e_out1) {
+        f32x4 sa = kc * e_c1c;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) sa += e_kv[j] * e_c1[j];
+        *(f32x4*)(e_out1 + off) = e_yv + sa * e_h;
+      }
+      if (e_out2 || e_nchw) {
+        f32x4 sb = kc * e_c2c;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (j < e_np) sb += e_kv[j] * e_c2[j];
+        const f32x4 o2 = e_yv + sb * e_h;
+        if (e_out2) *(f32x4*)(e_out2 + off) = o2;
+        if (e_nchw) {
+          float* o = e_nchw + ((size_t)b * 64 + Q * 4) * kPix + P;
+          o[0] = o2.x; o[kPix] = o2.y; o[2 * kPix] = o2.z; o[3 * kPix] = o2.w;
+        }
+      }
+    }
   }
   wait_vmcnt<0>();
   if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(hk.done + (rq * (4 / NB) + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(hk.done + (rq * 4 + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// elementwise / norm rows (ConvArgs::combine == 4 / 5) in the sixteen- / eight-workgroup layout: a lane's NB quads (see ew_row)
-template <int NB>
+// elementwise / norm rows (ConvArgs::combine == 4 / 5) in the sixteen-workgroup layout: a lane's one quad (see ew_row)
 __device__ __forceinline__ void ew_row16(const ConvArgs& a, int b, int cq, int rq, const Hook16& hk) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1485,61 +1465,41 @@ __device__ __forceinline__ void ew_row16(const ConvArgs& a, int b, int cq, int r
   const CombineArgs& m = a.cmb;
   const unsigned long long* const rl = hk.reloc;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int oa = wave >> 1, ob = wave & 1, oty = i16 >> 3, otx = i16 & 7;
+  const int Q = cq * 4 + kq, oa = wave >> 1, ob = wave & 1, oty = i16 >> 3, otx = i16 & 7;
   const int P = (rq * 4 + 2 * oty + oa) * 16 + 2 * otx + ob;
-  size_t off[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) off[k] = (((size_t)b * 16 + (cq * NB + k) * 4 + kq) * kPix + P) * 4;
+  const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
   const float* const yp = rel(rl, m.y);
   if (a.combine == 5) {
-    const float* const pa = rel(rl, m.k_prev[0]);
-    const float* const pb = m.n_prev > 1 ? rel(rl, m.k_prev[1]) : nullptr;
+    f32x4 d = *(const f32x4*)(rel(rl, m.k_prev[0]) + off);
+    const f32x4 yv = *(const f32x4*)(yp + off);
+    if (m.n_prev > 1) d -= *(const f32x4*)(rel(rl, m.k_prev[1]) + off);
     float sum = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      f32x4 d = *(const f32x4*)(pa + off[k]);
-      const f32x4 yv = *(const f32x4*)(yp + off[k]);
-      if (pb) d -= *(const f32x4*)(pb + off[k]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float r = d[i] / __builtin_fmaf(fabsf(yv[i]), m.rtol, m.atol);
-        sum = __builtin_fmaf(r, r, sum);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const float r = d[i] / __builtin_fmaf(fabsf(yv[i]), m.rtol, m.atol);
+      sum = __builtin_fmaf(r, r, sum);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) m.err_partials[((b * 4 + rq) * (4 / NB) + cq) * 4 + wave] = sum;
+    if (lane == 0) m.err_partials[(b * 16 + rq * 4 + cq) * 4 + wave] = sum;
   } else {
     const float hs = m.h_ptr ? *(ConstF*)m.h_ptr : 1.0f;
     float* const o1 = rel(rl, m.out1);
     float* const o2 = rel(rl, m.out2);
-    f32x4 s1[NB], s2[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      s1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (yp) s1[k] = *(const f32x4*)(yp + off[k]);
-      s2[k] = s1[k];
-    }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+    if (yp) s1 = *(const f32x4*)(yp + off);
+    f32x4 s2 = s1;
     for (int j = 0; j < m.n_prev; ++j) {
-      const float* const kp = rel(rl, m.k_prev[j]);
-      const float c1 = (m.c_dev ? ((ConstF*)m.c_dev)[j] : m.c1[j]) * hs;
-      const float c2 = m.c2[j] * hs;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const f32x4 kv = *(const f32x4*)(kp + off[k]);
-        s1[k] = fma4(kv, c1, s1[k]);
-        if (o2) s2[k] = fma4(kv, c2, s2[k]);
-      }
+      const f32x4 kv = *(const f32x4*)(rel(rl, m.k_prev[j]) + off);
+      s1 = fma4(kv, (m.c_dev ? ((ConstF*)m.c_dev)[j] : m.c1[j]) * hs, s1);
+      if (o2) s2 = fma4(kv, m.c2[j] * hs, s2);
     }
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      if (o1) *(f32x4*)(o1 + off[k]) = s1[k];
-      if (o2) *(f32x4*)(o2 + off[k]) = s2[k];
-    }
+    if (o1) *(f32x4*)(o1 + off) = s1;
+    if (o2) *(f32x4*)(o2 + off) = s2;
   }
   wait_vmcnt<0>();
   if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(hk.done + (rq * (4 / NB) + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(hk.done + (rq * 4 + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArgs pa) {
@@ -1597,30 +1557,37 @@ __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArg
       }
     }
     const Hook16 hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
-                       pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l), true};
-    if (a.combine >= 4) ew_row16<1>(a, b, cq, rq, hk);
-    else wino_layer16<1>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, b, cq, rq, smem, hk);
+                       pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l), true, false, nullptr};
+    if (a.combine >= 4) ew_row16(a, b, cq, rq, hk);
+    else wino_layer16<false>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, b, cq, rq, smem, hk);
     src = src_next;
     u = u_next;
   }
 }
 
-// The eight-workgroup walk (W16<2>): 256 workgroups = 32 groups of eight (one XCD each: logical ids 8 g .. 8 g + 7), a group walks
-// the samples g, g + 32 (two at a time, layer by layer in turn), then g + 64, g + 96, ...
-__global__ __launch_bounds__(512, 1) void wino_persist8_kernel(const PersistArgs pa) {
+// ---- batches 17 .. 64 (round 4): the sixteen-workgroup decomposition with FOUR samples per group and the layer's U resident in LDS.
+// The four-workgroup walk pays ~2.2 us of hand-off (stores acknowledged -> flags -> input tile -> first transform) on every 7.3 us
+// layer when a group has ONE sample, which is the configs' own batch of 64; it cannot interleave without more samples.  Finer
+// decompositions re-read U once per (sample, layer, workgroup) -- eight workgroups of (32 channels x 16 tiles) measured 10.0 us per
+// layer PAIR against 2 x 7.3: bound by L2 -> LDS delivery of U (256 KiB per workgroup and pair).  Here a group of sixteen workgroups
+// (16 channels x 16 tiles each; 16 groups, two per XCD) walks the samples g, g + 16, g + 32, g + 48 through a layer in turn: the
+// 64 KiB of U for the workgroup's channel tile are loaded ONCE per layer (prefetched into the chunk buffers the last sample's
+// consumers leave) and a sample's hand-off is covered by the three other samples' layers.  Layer code = the sixteen-workgroup walk's,
+// so every stored value is bit-identical to the other walks and to one launch per layer.
+__global__ __launch_bounds__(512, 1) void wino_persist16x_kernel(const PersistArgs pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lid = ((int)blockIdx.x & 7) * 32 + ((int)blockIdx.x >> 3);
-  const int group = lid >> 3, wg = lid & 7;
-  const int rq = wg >> 1, ct = wg & 1;
-  constexpr int n_groups = 32;
+  const int group = lid >> 4, wg = lid & 15;
+  const int rq = wg >> 2, cq = wg & 3;
+  constexpr int n_groups = 16;
   if (group >= pa.batch) return;   // (a whole group: its partners leave too)
   const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;
   if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool fence = false;
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < 16; ++p) {
     unsigned v = 0;
     int n = 0;
-    while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~7) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+    while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~15) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
       __builtin_amdgcn_s_sleep(2);
       if (++n > (1 << 23)) {
         __hip_atomic_store(pa.xcc_of + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1636,41 +1603,53 @@ __global__ __launch_bounds__(512, 1) void wino_persist8_kernel(const PersistArgs
   {
     typedef const __attribute__((address_space(4))) int ConstI;
     const int* skip = table[0].skip;
-    if (skip && *(ConstI*)skip) return;
-    if (pa.n_layers_ptr) {
+    if (skip && *(ConstI*)skip) return;   // an adaptive solver that finished while this launch was queued (uniform)
+    if (pa.n_layers_ptr) {   // a device-side controller picks the section of the table: {first row, rows}
       const int row0 = ((ConstI*)pa.n_layers_ptr)[0], n_dev = ((ConstI*)pa.n_layers_ptr)[1];
       if (row0 < 0 || n_dev <= 0 || row0 + n_dev > n_layers) return;
       table += row0;
       n_layers = n_dev;
     }
   }
-  for (int b = group; b < pa.batch; b += 2 * n_groups) {
-    const int n_interleaved = b + n_groups < pa.batch ? 2 : 1;
+  const float* u_res = nullptr;   // the U that is in LDS (or on its way there)
+  for (int b = group; b < pa.batch; b += 4 * n_groups) {
+    int n_il = (pa.batch - b + n_groups - 1) / n_groups;
+    n_il = n_il > 4 ? 4 : n_il;
     const float* src = table[0].src1;
-    const float* u = table[0].w_wino;
     for (int l = 0; l < n_layers; ++l) {
       typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
       const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
       const float* src_next = src;
-      const float* u_next = u;
       if (l + 1 < n_layers) {
         src_next = table[l + 1].src1;
-        u_next = table[l + 1].w_wino;
         if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
           const unsigned v = __builtin_nontemporal_load((const unsigned*)&table[l + 1] + threadIdx.x * 16);
           asm volatile("" ::"v"(v));
         }
       }
-#pragma unroll 1
-      for (int s = 0; s < n_interleaved; ++s) {
-        const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
-        const Hook16 hk = {pa.done + (size_t)bs * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
-                           pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l), n_interleaved == 1};
-        if (a.combine >= 4) ew_row16<2>(a, bs, ct, rq, hk);
-        else wino_layer16<2>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, bs, ct, rq, smem, hk);
+      const bool conv = a.combine < 4;
+      const float* const u = conv ? a.w_wino : nullptr;
+      // the next conv row's U (elementwise rows in between do not touch the buffers)
+      const float* u_nx = nullptr;
+      if (conv) {
+        for (int k = l + 1; k < n_layers && k <= l + 4; ++k) {
+          const ConvArgs& an = *(const ConvArgs*)((ConstArgs*)table + k);
+          if (an.combine < 4) { u_nx = an.w_wino; break; }
+        }
+        if (u_nx == u) u_nx = nullptr;   // (the same weights again: they simply stay)
       }
+#pragma unroll 1
+      for (int s = 0; s < n_il; ++s) {
+        const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
+        const bool last = s == n_il - 1;
+        const Hook16 hk = {pa.done + (size_t)bs * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
+                           pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l), n_il == 1, conv && s == 0 && u != u_res,
+                           last ? u_nx : nullptr};
+        if (!conv) ew_row16(a, bs, cq, rq, hk);
+        else wino_layer16<true>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, bs, cq, rq, smem, hk);
+      }
+      if (conv) u_res = u_nx ? u_nx : u;
       src = src_next;
-      u = u_next;
     }
   }
 }
@@ -1702,15 +1681,15 @@ int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, un
   return ODEHIP_OK;
 }
 
-int launch_wino_persist8(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                         float* out_nchw, hipStream_t stream, const int* n_layers_ptr, const unsigned long long* reloc) {
+int launch_wino_persist16x(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
+                           float* out_nchw, hipStream_t stream, const int* n_layers_ptr, const unsigned long long* reloc) {
   static bool attr_set = false;
-  ODEHIP_REQUIRE(batch >= 1, "wino_persist8: batch %d out of range", batch);
+  ODEHIP_REQUIRE(batch >= 1, "wino_persist16x: batch %d out of range", batch);
   if (!attr_set) {
-    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist16x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = 0;
-    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist8_kernel, 512, W16<2>::kLds));
-    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist8: the kernel does not fit a CU");
+    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist16x_kernel, 512, kWino16xLds));
+    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist16x: the kernel does not fit a CU");
     attr_set = true;
   }
   PersistArgs pa;
@@ -1719,9 +1698,9 @@ int launch_wino_persist8(const ConvArgs* table_dev, int n_layers, int batch, uns
   pa.out_nchw = out_nchw;
   pa.n_layers_ptr = n_layers_ptr;
   pa.reloc = reloc;
-  static const int sleep_env = [] { const char* e = getenv("ODEHIP_PERSIST8_SLEEP"); return e ? atoi(e) : -1; }();
-  pa.sleep6 = sleep_env >= 0 ? sleep_env : 5;   // (only used by a group that walks one sample)
-  hipLaunchKernelGGL(wino_persist8_kernel, dim3(256), dim3(512), W16<2>::kLds, stream, pa);
+  static const int sleep_env = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : -1; }();
+  pa.sleep6 = sleep_env >= 0 ? sleep_env : 5;   // (only a group that walks ONE sample sleeps)
+  hipLaunchKernelGGL(wino_persist16x_kernel, dim3(256), dim3(512), kWino16xLds, stream, pa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

@@ -591,7 +591,7 @@ extern "C" size_t odehip_dopri5_workspace_bytes(const odehip_convstack* f, int b
   if (!f || batch <= 0 || n_times <= 0) return 0;
   const size_t st = al256((size_t)batch * f->channels[0] * kPix * 4);
   const size_t hid = al256((size_t)batch * max_hidden(f) * kPix * 4);
-  const size_t np = (size_t)batch * (f->channels[0] / 32) * 2 * 4;
+  const size_t np = (size_t)batch * (f->channels[0] / 32) * 2 * 4 * 4;   // (four times the per-layer kernels' count: the sixteen-workgroup walks write 64 per sample)
   return al256(sizeof(DopriState)) + al256((size_t)n_times * 8) + 3 * al256((np > 1024 ? np : 1024) * 4) + 2 * hid + 10 * st +
          al256(persist_sync_bytes(batch)) + al256(16 * 8);
 }
@@ -654,7 +654,8 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
     if ((rc = probe.begin(f, nullptr, 1)) != ODEHIP_OK) return rc;
     walk_ok = probe.recording();
   }
-  const int n_conv_partials = walk_ok && persist_partials_per_sample(batch) == 64 ? batch * 64 : batch * (C / 32) * 2 * 4;
+  const int pps = walk_ok ? persist_partials_per_sample(batch) : 16;
+  const int n_conv_partials = pps > 16 ? batch * pps : batch * (C / 32) * 2 * 4;
   const int red_grid = 256;
 
   // the context of this solve: on the stack for a synchronous call, in a free slot for an asynchronous one
@@ -677,6 +678,10 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   DopriState* state = (DopriState*)take(sizeof(DopriState));
   double* t_dev = (double*)take((size_t)n_times * 8);
   const size_t pbytes = (size_t)(n_conv_partials > 1024 ? n_conv_partials : 1024) * 4;
+  {
+    const size_t np2 = (size_t)batch * (C / 32) * 32;   // what odehip_dopri5_workspace_bytes reserves per array (at least 1024)
+    ODEHIP_REQUIRE((size_t)n_conv_partials <= (np2 > 1024 ? np2 : 1024), "odeint_dopri5: %d error-norm partials exceed the workspace", n_conv_partials);
+  }
   float* part0 = (float*)take(pbytes);
   float* part1 = (float*)take(pbytes);
   float* part2 = (float*)take(pbytes);
@@ -808,7 +813,7 @@ static int dopri5_forward(const odehip_convstack* f, const float* z0_nchw, const
   for (int i = 0; i < 7; ++i) cx.k[i] = k[i];
   cx.psync = psync; cx.reloc = reloc;
   cx.saving = saving; cx.global_norm = global_norm;
-  cx.partials64 = n_conv_partials == batch * 64 && n_conv_partials != batch * (C / 32) * 2 * 4;
+  cx.partials64 = n_conv_partials != batch * (C / 32) * 2 * 4;   // (the walks' 64 or 32 partials per sample)
   cx.bl_st = BL.st; cx.bl_hid = BL.hid; cx.bl_nh = BL.NH;
   cx.fa = fa;
   cx.n4 = n4;

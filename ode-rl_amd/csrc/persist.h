@@ -66,7 +66,7 @@ class PersistScope {
   const unsigned* abort_word_ = nullptr;
   const ConvArgs* table_ = nullptr;   // device table of the last persistent launch
   int table_rows_ = 0;
-  bool table_wide_ = false, table_adaptive_ = false, table_small16_ = false, table_walk8_ = false;
+  bool table_wide_ = false, table_adaptive_ = false, table_small16_ = false;
 };
 
 // Whole-trajectory launches that need no cross-workgroup hand-off (bf16: one workgroup per sample) obey the same on/off switch

@@ -195,26 +195,16 @@ static bool walk16_on() {
   return on16;
 }
 
-// the eight-workgroup walk (conv_wino.hip, wino_persist8_kernel): batches 17 .. walk8_max(), two samples per group above 32
-static bool walk8_on() {
-  static const bool on8 = [] { const char* e = getenv("ODEHIP_PERSIST8"); return !(e && e[0] == '0'); }();
-  return on8;
-}
-static int walk8_max() {
-  static const int m = [] { const char* e = getenv("ODEHIP_PERSIST8_MAX"); return e ? atoi(e) : 64; }();
-  return m;
-}
-static bool walk8_adaptive() {
-  static const bool on = [] { const char* e = getenv("ODEHIP_PERSIST8_ADAPTIVE"); return e && e[0] == '1'; }();
-  return on;
+// batches 17 .. walk16x_max(): the sixteen-workgroup decomposition with four samples per group and U resident (wino_persist16x_kernel)
+static int walk16x_max() {
+  static const int m = [] { const char* e = getenv("ODEHIP_PERSIST16X_MAX"); return e ? atoi(e) : 64; }();
+  return walk16_on() ? m : 0;
 }
 
 // (see odehip_internal.h) -- takes the lock: not to be called inside a PersistScope
 int persist_partials_per_sample(int batch) {
   std::lock_guard<std::mutex> g(g_persist.mu);
-  if (batch <= 16 && walk16_on() && persist_available()) return 64;
-  if (batch > 16 && batch <= walk8_max() && walk8_on() && walk8_adaptive() && persist_available()) return 32;
-  return 16;
+  return (batch <= 16 || batch <= walk16x_max()) && walk16_on() && persist_available() ? 64 : 16;
 }
 
 bool persist_switch_on() {
@@ -408,34 +398,31 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     int rc;
     // batches up to 16: forward tables of a 64-channel stack take the sixteen-workgroups-per-sample walk (a layer's matrix work is
     // split four times finer; bit-identical results)
-    bool small16 = false, walk8 = false;
-    const bool want16 = table && !wide && batch <= 16 && walk16_on();
-    const bool want8 = table && !wide && batch > 16 && batch <= walk8_max() && walk8_on() && (!adaptive || walk8_adaptive());
-    if (want16 || want8) {
-      bool ok = true;
-      for (int i = 0; i < rec_.count && ok; ++i) {
+    bool small16 = false;
+    const bool x16 = batch > 16 && batch <= walk16x_max();
+    if (table && !wide && (batch <= 16 || x16) && walk16_on()) {
+      small16 = true;
+      for (int i = 0; i < rec_.count && small16; ++i) {
         const ConvArgs& a = rec_.items[i];
         if (a.combine >= 4) continue;   // elementwise / norm rows
-        ok = a.qin == 16 && a.qout == 16 &&
-             (a.combine == 0 || a.combine == 2 || a.combine == 3 ||
-              (a.combine == 1 && (((a.h_by_value || eval_walk_) && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order) ||
-                                  (a.cmb.order == 1 && !(a.cmb.err_partials && (a.cmb.out2 || a.cmb.out2_nchw))))));
+        small16 = a.qin == 16 && a.qout == 16 &&
+                  (a.combine == 0 || a.combine == 2 || a.combine == 3 ||
+                   (a.combine == 1 && (((a.h_by_value || eval_walk_) && a.cmb.n_prev <= 3 && !a.cmb.err_partials && !a.cmb.order) ||
+                                       (a.cmb.order == 1 && !(a.cmb.err_partials && (a.cmb.out2 || a.cmb.out2_nchw))))));
         // (a reverse-sweep row that falls to the shared epilogue must not carry relocatable pointers: the adaptive drivers keep to two
         // constant-coefficient targets)
       }
-      small16 = want16 && ok;
-      walk8 = want8 && ok;
-      if (adaptive && !ok) {   // an adaptive table counts on 64 / 32 partials per sample here (persist_partials_per_sample)
-        set_error("persistent walk: an adaptive table of batch %d has a row the sixteen- / eight-workgroup walk does not take", batch);
+      if (adaptive && !small16) {   // an adaptive table counts on 64 partials per sample here (persist_partials_per_sample)
+        set_error("persistent walk: an adaptive table of batch %d has a row the sixteen-workgroup walk does not take", batch);
         return ODEHIP_EINVAL;
       }
     }
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
-      if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream,
-                                              rows_dev_, reloc_dev_);
-      else if (walk8) rc = launch_wino_persist8(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream,
-                                                rows_dev_, reloc_dev_);
+      if (small16 && x16) rc = launch_wino_persist16x(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
+                                                      stream, rows_dev_, reloc_dev_);
+      else if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream,
+                                                   rows_dev_, reloc_dev_);
       else
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
                                kPersistGrid, stream, wide, adaptive, rows_dev_, reloc_dev_);
@@ -449,7 +436,6 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
         table_wide_ = wide;
         table_adaptive_ = adaptive;
         table_small16_ = small16;
-        table_walk8_ = walk8;
         return rc;
       }
       g_persist.enabled = 0;  // the launch was refused: one launch per layer from now on
@@ -473,12 +459,12 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
 int PersistScope::relaunch(int batch, unsigned* sync, hipStream_t stream, bool sync_is_zero) {
   ODEHIP_REQUIRE(launched_ && table_ && !volatile_, "persistent relaunch without a table");
   if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
-  const int rc = table_small16_
+  const int rc = table_small16_ && batch > 16
+                     ? launch_wino_persist16x(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
+                                              stream, rows_dev_, reloc_dev_)
+                     : table_small16_
                      ? launch_wino_persist16(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
                                              stream, rows_dev_, reloc_dev_)
-                     : table_walk8_
-                     ? launch_wino_persist8(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
-                                            stream, rows_dev_, reloc_dev_)
                      : launch_wino_persist(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
                                            kPersistGrid, stream, table_wide_, table_adaptive_, rows_dev_, reloc_dev_);
   if (rc == ODEHIP_OK) ++g_persist.launches;
