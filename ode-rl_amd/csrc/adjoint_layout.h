@@ -50,9 +50,8 @@ struct AdjLayout {
   float* gp(const void* ws, int slot, int s, int l) const {
     return p(ws, off_slots + (size_t)slot * slot_bytes + 7 * st + 7 * (size_t)NH * hid + ((size_t)s * (NH + 1) + l) * hid);
   }
-  // floats per partial array: the per-layer kernels write n_part (16 per sample), the sixteen-workgroup walk 64 per sample (batch <= 16),
-  // also at batches 17 .. 64 (wino_persist16x_kernel)
-  int part_stride() const { return 4 * n_part > 1024 ? 4 * n_part : 1024; }
+  // floats per partial array: the per-layer kernels write n_part, the sixteen-workgroup walk 64 per sample (batch <= 16)
+  int part_stride() const { return n_part > 1024 ? n_part : 1024; }
   float* part(const void* ws, int j) const { return p(ws, off_part + (size_t)j * part_stride() * 4); }
 };
 

@@ -1039,9 +1039,6 @@ constexpr int k16Raw = 8 * 1024;   // raw chunk: 4 quads x 2 KiB: 6 rows x 20 sl
 constexpr int k16V = 16 * 1024;    // V chunk: 16 xi x [quad 4][tile 16][4 ci]
 constexpr int k16X = 8 * 1024;     // exchange: [a 2][col 4][lane 64] quads
 constexpr int kWino16Lds = 2 * k16U + 2 * k16Raw + 2 * k16V + k16X;
-// URES (round 4, wino_persist16x_kernel): the layer's WHOLE U for this 16-channel tile stays in LDS (4 chunks, 64 KiB) while the group
-// walks up to four samples through the layer
-constexpr int kWino16xLds = 4 * k16U + 2 * k16Raw + 2 * k16V + k16X;   // 120 KiB
 
 struct Hook16 {
   unsigned* done;      // the sample's 64 flag words
@@ -1053,10 +1050,6 @@ struct Hook16 {
   int sleep6;
   const unsigned long long* reloc;   // relocation bases of an adaptive table (rel()), or null
   unsigned wait_target;              // target, or target - 1 for a row that does not depend on the row in front of it (dep_back)
-  // URES only:
-  bool solo;                         // the group walks one sample: the producers sleep in front of their first poll
-  bool load_u;                       // this layer's U is not in LDS yet (the first sample of a round when nothing was prefetched)
-  const float* u_next;               // the last sample of a round: the next conv row's U, loaded into the chunk buffers as they fall free
 };
 
 __device__ __forceinline__ void wait_done16(const Hook16& hk, int lo_word, int hi_word) {
@@ -1077,14 +1070,12 @@ __device__ __forceinline__ void wait_done16(const Hook16& hk, int lo_word, int h
   if (hk.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-template <bool URES>
 __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, const float* __restrict__ p_u, const ConvArgs& a, int b,
                                              int cq, int rq, char* smem, const Hook16& hk) {
-  constexpr int kNUB = URES ? 4 : 2;   // U chunk buffers
   char* const Ub = smem;
-  char* const Rb = smem + kNUB * k16U;
-  char* const Vb = smem + kNUB * k16U + 2 * k16Raw;
-  char* const Xb = smem + kNUB * k16U + 2 * k16Raw + 2 * k16V;
+  char* const Rb = smem + 2 * k16U;
+  char* const Vb = smem + 2 * k16U + 2 * k16Raw;
+  char* const Xb = smem + 2 * k16U + 2 * k16Raw + 2 * k16V;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1109,14 +1100,13 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
     }
     // U: the chunk's 64 (xi, quad) pieces of this channel half are 256 B each, 512 B apart: one instruction moves four of them
     const int vu = (lane >> 4) * 512 + half * 256 + (lane & 15) * 16;
-    auto issue_u_from = [&](const __amdgpu_buffer_rsrc_t& r, int c, int buf) {
+    auto issue_u = [&](int c, int buf) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int p = pw * 4 + g;   // pieces 4p .. 4p + 3
-        dma16(r, Ub + buf * k16U + p * 1024, vu, c * kWU + p * 2048);
+        dma16(ru, Ub + buf * k16U + p * 1024, vu, c * kWU + p * 2048);
       }
     };
-    auto issue_u = [&](int c, int buf) { issue_u_from(ru, c, buf); };
     auto issue_raw = [&](int c, int buf) {
 #pragma unroll
       for (int p = 0; p < 2; ++p)
@@ -1149,46 +1139,6 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
       *(f32x4*)(v + 2 * 1024) = pk_sub(T[2], T[1]);
       *(f32x4*)(v + 3 * 1024) = pk_sub(T[1], T[3]);
     };
-    if constexpr (URES) {
-      // U is RESIDENT: chunk c of the layer's U lives in buffer c for the whole round (up to four samples).  load_u: nothing was
-      // prefetched (first row of a walk, or the row before did not know this one): all four chunks are requested now.  u_next (the last
-      // sample of the round): the next conv row's chunks go into the buffers as this layer's consumers leave them -- chunk c - 1 behind
-      // barrier [c], chunk 3 behind the exchange barrier -- so the next round starts with its weights in place.
-      // DMA order per wave: [U_0..U_3 (16)] | raw_0 (2) | raw_1 (2) | per iteration c: [U'_{c-1} (4)] | raw_{c+2} (2) | ... | [U'_2] | [U'_3]
-      const bool pf = hk.u_next != nullptr;
-      const __amdgpu_buffer_rsrc_t run = make_rsrc((const char*)(pf ? hk.u_next : p_u) + (size_t)ct * u_tile_bytes, u_tile_bytes);
-      if (hk.load_u) {
-#pragma unroll
-        for (int c = 0; c < nchunk; ++c) issue_u(c, c);
-      }
-      if (!hk.first) {
-        if (hk.solo && hk.wait_target == hk.target)
-          for (int i = 0; i < hk.sleep6; ++i) __builtin_amdgcn_s_sleep(6);
-        const int lo = rq > 0 ? (rq - 1) * 16 : 0, hi = rq < 3 ? (rq + 2) * 16 : 64;
-        wait_done16(hk, lo, hi);
-      }
-      issue_raw(0, 0);
-      issue_raw(1, 1);
-      wait_vmcnt<2>();   // raw_0 landed, and with it every older request: this layer's U (loaded now or prefetched by the last round)
-      transform(0, 0);
-#pragma unroll
-      for (int c = 0; c < nchunk; ++c) {
-        __builtin_amdgcn_s_barrier();  // [c]
-        if (pf && c >= 1) issue_u_from(run, c - 1, c - 1);   // buffer c - 1: the consumers are through chunk c - 1
-        if (c + 1 < nchunk) {
-          if (c + 2 < nchunk) {
-            issue_raw(c + 2, c & 1);
-            if (pf && c >= 1) wait_vmcnt<6>(); else wait_vmcnt<2>();   // raw_{c+1} landed (younger: [U'_{c-1}], raw_{c+2})
-          } else {
-            if (pf) wait_vmcnt<4>(); else wait_vmcnt<0>();   // raw_3 landed (younger: U'_1)
-          }
-          transform((c + 1) & 1, (c + 1) & 1);
-        }
-      }
-      __builtin_amdgcn_s_barrier();    // [X] the consumers' exchange
-      if (pf) issue_u_from(run, 3, 3);
-      return;
-    }
     // DMA order per wave: U_0 (4) | raw_0 (2) | raw_1 (2) | then per iteration c: U_{c+1} (4) | raw_{c+2} (2)
     issue_u(0, 0);
     if (!hk.first) {
@@ -1340,7 +1290,7 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
 #pragma unroll
   for (int c = 0; c < nchunk; ++c) {
     __builtin_amdgcn_s_barrier();  // [c]
-    const char* u = Ub + (URES ? c : (c & 1)) * k16U + frag_off;
+    const char* u = Ub + (c & 1) * k16U + frag_off;
     const char* v = Vb + (c & 1) * k16V + frag_off;
     f32x4 wf[4], xf[4];
 #pragma unroll
@@ -1557,100 +1507,11 @@ __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArg
       }
     }
     const Hook16 hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
-                       pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l), true, false, nullptr};
+                       pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l)};
     if (a.combine >= 4) ew_row16(a, b, cq, rq, hk);
-    else wino_layer16<false>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, b, cq, rq, smem, hk);
+    else wino_layer16(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, b, cq, rq, smem, hk);
     src = src_next;
     u = u_next;
-  }
-}
-
-// ---- batches 17 .. 64 (round 4): the sixteen-workgroup decomposition with FOUR samples per group and the layer's U resident in LDS.
-// The four-workgroup walk pays ~2.2 us of hand-off (stores acknowledged -> flags -> input tile -> first transform) on every 7.3 us
-// layer when a group has ONE sample, which is the configs' own batch of 64; it cannot interleave without more samples.  Finer
-// decompositions re-read U once per (sample, layer, workgroup) -- eight workgroups of (32 channels x 16 tiles) measured 10.0 us per
-// layer PAIR against 2 x 7.3: bound by L2 -> LDS delivery of U (256 KiB per workgroup and pair).  Here a group of sixteen workgroups
-// (16 channels x 16 tiles each; 16 groups, two per XCD) walks the samples g, g + 16, g + 32, g + 48 through a layer in turn: the
-// 64 KiB of U for the workgroup's channel tile are loaded ONCE per layer (prefetched into the chunk buffers the last sample's
-// consumers leave) and a sample's hand-off is covered by the three other samples' layers.  Layer code = the sixteen-workgroup walk's,
-// so every stored value is bit-identical to the other walks and to one launch per layer.
-__global__ __launch_bounds__(512, 1) void wino_persist16x_kernel(const PersistArgs pa) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lid = ((int)blockIdx.x & 7) * 32 + ((int)blockIdx.x >> 3);
-  const int group = lid >> 4, wg = lid & 15;
-  const int rq = wg >> 2, cq = wg & 3;
-  constexpr int n_groups = 16;
-  if (group >= pa.batch) return;   // (a whole group: its partners leave too)
-  const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;
-  if (threadIdx.x == 0) __hip_atomic_store(pa.xcc_of + lid, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  bool fence = false;
-  for (int p = 0; p < 16; ++p) {
-    unsigned v = 0;
-    int n = 0;
-    while ((v = __hip_atomic_load(pa.xcc_of + (lid & ~15) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++n > (1 << 23)) {
-        __hip_atomic_store(pa.xcc_of + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *pa.host_err = 2;
-        break;
-      }
-    }
-    fence |= (v != my_xcc);
-  }
-  fence = __builtin_amdgcn_readfirstlane(fence);
-  const ConvArgs* table = pa.table;
-  int n_layers = pa.n_layers;
-  {
-    typedef const __attribute__((address_space(4))) int ConstI;
-    const int* skip = table[0].skip;
-    if (skip && *(ConstI*)skip) return;   // an adaptive solver that finished while this launch was queued (uniform)
-    if (pa.n_layers_ptr) {   // a device-side controller picks the section of the table: {first row, rows}
-      const int row0 = ((ConstI*)pa.n_layers_ptr)[0], n_dev = ((ConstI*)pa.n_layers_ptr)[1];
-      if (row0 < 0 || n_dev <= 0 || row0 + n_dev > n_layers) return;
-      table += row0;
-      n_layers = n_dev;
-    }
-  }
-  const float* u_res = nullptr;   // the U that is in LDS (or on its way there)
-  for (int b = group; b < pa.batch; b += 4 * n_groups) {
-    int n_il = (pa.batch - b + n_groups - 1) / n_groups;
-    n_il = n_il > 4 ? 4 : n_il;
-    const float* src = table[0].src1;
-    for (int l = 0; l < n_layers; ++l) {
-      typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
-      const ConvArgs& a = *(const ConvArgs*)((ConstArgs*)table + l);
-      const float* src_next = src;
-      if (l + 1 < n_layers) {
-        src_next = table[l + 1].src1;
-        if (threadIdx.x < (sizeof(ConvArgs) + 63) / 64) {
-          const unsigned v = __builtin_nontemporal_load((const unsigned*)&table[l + 1] + threadIdx.x * 16);
-          asm volatile("" ::"v"(v));
-        }
-      }
-      const bool conv = a.combine < 4;
-      const float* const u = conv ? a.w_wino : nullptr;
-      // the next conv row's U (elementwise rows in between do not touch the buffers)
-      const float* u_nx = nullptr;
-      if (conv) {
-        for (int k = l + 1; k < n_layers && k <= l + 4; ++k) {
-          const ConvArgs& an = *(const ConvArgs*)((ConstArgs*)table + k);
-          if (an.combine < 4) { u_nx = an.w_wino; break; }
-        }
-        if (u_nx == u) u_nx = nullptr;   // (the same weights again: they simply stay)
-      }
-#pragma unroll 1
-      for (int s = 0; s < n_il; ++s) {
-        const int bs = __builtin_amdgcn_readfirstlane(b + s * n_groups);
-        const bool last = s == n_il - 1;
-        const Hook16 hk = {pa.done + (size_t)bs * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
-                           pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l), n_il == 1, conv && s == 0 && u != u_res,
-                           last ? u_nx : nullptr};
-        if (!conv) ew_row16(a, bs, cq, rq, hk);
-        else wino_layer16<true>(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, bs, cq, rq, smem, hk);
-      }
-      if (conv) u_res = u_nx ? u_nx : u;
-      src = src_next;
-    }
   }
 }
 
@@ -1677,30 +1538,6 @@ int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, un
   static const int sleep_env = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : -1; }();
   pa.sleep6 = sleep_env >= 0 ? sleep_env : (batch > 8 ? 5 : 4);
   hipLaunchKernelGGL(wino_persist16_kernel, dim3(256), dim3(512), kWino16Lds, stream, pa);
-  ODEHIP_CHECK_HIP(hipGetLastError());
-  return ODEHIP_OK;
-}
-
-int launch_wino_persist16x(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                           float* out_nchw, hipStream_t stream, const int* n_layers_ptr, const unsigned long long* reloc) {
-  static bool attr_set = false;
-  ODEHIP_REQUIRE(batch >= 1, "wino_persist16x: batch %d out of range", batch);
-  if (!attr_set) {
-    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)wino_persist16x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    int per_cu = 0;
-    ODEHIP_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wino_persist16x_kernel, 512, kWino16xLds));
-    ODEHIP_REQUIRE(per_cu >= 1, "wino_persist16x: the kernel does not fit a CU");
-    attr_set = true;
-  }
-  PersistArgs pa;
-  memset(&pa, 0, sizeof(pa));
-  pa.table = table_dev; pa.n_layers = n_layers; pa.batch = batch; pa.done = done; pa.xcc_of = xcc_of; pa.host_err = host_err_dev;
-  pa.out_nchw = out_nchw;
-  pa.n_layers_ptr = n_layers_ptr;
-  pa.reloc = reloc;
-  static const int sleep_env = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : -1; }();
-  pa.sleep6 = sleep_env >= 0 ? sleep_env : 5;   // (only a group that walks ONE sample sleeps)
-  hipLaunchKernelGGL(wino_persist16x_kernel, dim3(256), dim3(512), kWino16xLds, stream, pa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

@@ -133,9 +133,6 @@ int launch_ew_row(const ConvArgs& a, hipStream_t stream);
 // forward tables of a 64-channel stack at batch <= 16: sixteen workgroups per sample (conv_wino.hip, wino_persist16_kernel)
 int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
                           float* out_nchw, hipStream_t stream, const int* n_layers_ptr = nullptr, const unsigned long long* reloc = nullptr);
-// batches 17 .. 64: the same decomposition, four samples per group of sixteen workgroups, U resident in LDS (wino_persist16x_kernel)
-int launch_wino_persist16x(const ConvArgs* table_dev, int n_layers, int batch, unsigned* done, unsigned* xcc_of, unsigned* host_err_dev,
-                           float* out_nchw, hipStream_t stream, const int* n_layers_ptr = nullptr, const unsigned long long* reloc = nullptr);
 // error-norm / norm-row partials per sample that a walk of `batch` samples writes: 64 on the sixteen-workgroup walk (batch <= 16, walk
 // available and not switched off), else the per-layer kernels' 16 (64-channel stacks).  Decided BEFORE the rows run: a controller must
 // know how many partials to add.

@@ -195,16 +195,10 @@ static bool walk16_on() {
   return on16;
 }
 
-// batches 17 .. walk16x_max(): the sixteen-workgroup decomposition with four samples per group and U resident (wino_persist16x_kernel)
-static int walk16x_max() {
-  static const int m = [] { const char* e = getenv("ODEHIP_PERSIST16X_MAX"); return e ? atoi(e) : 64; }();
-  return walk16_on() ? m : 0;
-}
-
 // (see odehip_internal.h) -- takes the lock: not to be called inside a PersistScope
 int persist_partials_per_sample(int batch) {
   std::lock_guard<std::mutex> g(g_persist.mu);
-  return (batch <= 16 || batch <= walk16x_max()) && walk16_on() && persist_available() ? 64 : 16;
+  return batch <= 16 && walk16_on() && persist_available() ? 64 : 16;
 }
 
 bool persist_switch_on() {
@@ -399,8 +393,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     // batches up to 16: forward tables of a 64-channel stack take the sixteen-workgroups-per-sample walk (a layer's matrix work is
     // split four times finer; bit-identical results)
     bool small16 = false;
-    const bool x16 = batch > 16 && batch <= walk16x_max();
-    if (table && !wide && (batch <= 16 || x16) && walk16_on()) {
+    if (table && !wide && batch <= 16 && walk16_on()) {
       small16 = true;
       for (int i = 0; i < rec_.count && small16; ++i) {
         const ConvArgs& a = rec_.items[i];
@@ -419,10 +412,8 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     }
     if (table) {
       if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
-      if (small16 && x16) rc = launch_wino_persist16x(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
-                                                      stream, rows_dev_, reloc_dev_);
-      else if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream,
-                                                   rows_dev_, reloc_dev_);
+      if (small16) rc = launch_wino_persist16(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw, stream,
+                                              rows_dev_, reloc_dev_);
       else
       rc = launch_wino_persist(table, rec_.count, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, out_nchw,
                                kPersistGrid, stream, wide, adaptive, rows_dev_, reloc_dev_);
@@ -459,10 +450,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
 int PersistScope::relaunch(int batch, unsigned* sync, hipStream_t stream, bool sync_is_zero) {
   ODEHIP_REQUIRE(launched_ && table_ && !volatile_, "persistent relaunch without a table");
   if (!sync_is_zero) ODEHIP_CHECK_HIP(hipMemsetAsync(sync, 0, persist_sync_bytes(batch), stream));
-  const int rc = table_small16_ && batch > 16
-                     ? launch_wino_persist16x(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
-                                              stream, rows_dev_, reloc_dev_)
-                     : table_small16_
+  const int rc = table_small16_
                      ? launch_wino_persist16(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,
                                              stream, rows_dev_, reloc_dev_)
                      : launch_wino_persist(table_, table_rows_, batch, sync, sync + (size_t)batch * kPersistDoneStride, g_persist.host_err_dev, nullptr,

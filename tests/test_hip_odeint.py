@@ -427,9 +427,9 @@ def test_persistent_fixed_grid_adjoint_gives_identical_gradients(cuda):
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch,rtol", [(64, 1e-4), (8, 1e-5), (100, 1e-4)])
 def test_persistent_dopri5_attempts_are_bit_identical(cuda, batch, rtol):
-    """The six evaluations of a dopri5 attempt as one persistent launch.  On the four-workgroup walk (batch > 64) the error-norm
+    """The six evaluations of a dopri5 attempt as one persistent launch.  On the four-workgroup walk (batch > 16) the error-norm
     partials land in the slots of the per-layer launches, so the controller takes the same decisions and the trajectory is equal
-    bit for bit; the sixteen-workgroup walks (batch <= 64) sum 64 partials per sample instead of 16 (see below)."""
+    bit for bit; the sixteen-workgroup walk (batch <= 16) sums 64 partials per sample instead of 16 (see below)."""
     import ode_rl_amd
     lib = ode_rl_amd._lib.load()
     torch.manual_seed(13)
@@ -445,10 +445,10 @@ def test_persistent_dopri5_attempts_are_bit_identical(cuda, batch, rtol):
             n0 = lib.odehip_persistent_trajectory_launches()
             out = ode_rl_amd.odeint(f, z0, t, rtol=rtol, atol=1e-5, method="dopri5")
             stats = dict(ode_rl_amd.last_stats)
-        if batch > 64:
+        if batch > 16:
             assert torch.equal(out, ref) and stats == ref_stats
         else:
-            # batches up to 64 take the sixteen-workgroup walks (<= 16: one sample per group; 17 .. 64: four, U resident): every stored value of a layer is still bit-identical, but the error
+            # batches up to 16 take the sixteen-workgroup walk: every stored value of a layer is still bit-identical, but the error
             # norm is the sum of 64 partials per sample instead of 16 -- the ratio, hence the next step size, moves in its last bits
             assert (stats["nfe"], stats["n_accept"], stats["n_reject"]) == (ref_stats["nfe"], ref_stats["n_accept"], ref_stats["n_reject"])
             assert all(abs(a[1] - b[1]) <= 1e-5 * abs(b[1]) for a, b in zip(stats["accepted"], ref_stats["accepted"]))
