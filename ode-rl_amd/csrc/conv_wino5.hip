@@ -17,7 +17,16 @@
 //              threads per (tile, channel quad) -- (3 of the 6 V columns) x (2 of the 4 channels) -- 72 packed-fp32 VALU
 //              instructions, 30 ds_read_b64 and 18 ds_write_b64 each.
 // One s_barrier per chunk.  LDS: U[2] + V[2] 144 KiB + raw[2] 16 KiB = 160 KiB.
+//
+// SPLIT (round 4; small batches -- the reference trains at batch 4, configs.yaml:7): a launch is a serial chain over the K = cin / 8
+// chunks (33 us for 128 input channels however small the batch: ~12 us fixed + 16 x 1.3 us) on (cout / 16) x batch workgroups -- 32 or 16
+// of 256 CUs at batch 4.  With SPLIT, S workgroups share an output tile: each walks K / S chunks, writes its partial 2x2 outputs to a
+// library-owned workspace and counts itself in (one counter per tile and consumer wave); the wave that arrives LAST adds the S
+// partials in split order (a fixed order: deterministic, no float atomics), then bias and the usual epilogue.  The S workgroups have
+// consecutive logical ids, i.e. one XCD, whose L2 is the coherence point of the hand-off (stores acknowledged, agent-scope counter,
+// sc1 loads); every workgroup publishes the XCD it really runs on and a tile whose workgroups differ adds agent-scope fences.
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "conv_common.h"
 #include "pack_elems.h"
@@ -87,8 +96,16 @@ __device__ __forceinline__ float at_coef(int row, int i) {
   return i == 0 ? 0.0f : (i == 1 ? 1.0f : (i == 2 ? -1.0f : (i == 3 ? 2.0f : (i == 4 ? -2.0f : 1.0f))));
 }
 
-template <bool DBG>  // DBG: ablation bits in a.debug (tools/conv5_microbench.py): 256 no transform, 512 no DMA, 1024 no fragment reads, 2048 no MFMA
-__global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) {
+struct Split5 {
+  int S;               // workgroups per output tile (1: no split)
+  float* part;         // [tile][split][wave 4][e 4][lane 64] quads
+  unsigned* count;     // [tile][wave 4]: splits that have delivered (reset by the last one)
+  unsigned* xcc;       // [workgroup]: epoch << 4 | XCC_ID + 1
+  unsigned epoch;
+};
+
+template <bool DBG, bool SPLIT>  // DBG: ablation bits in a.debug (tools/conv5_microbench.py): 256 no transform, 512 no DMA, 1024 no fragment reads, 2048 no MFMA
+__global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a, const Split5 sp5) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // regions: [U0 | V0 | U1 | V1 | raw0 | raw1]: buffer b of U / V at b * (k5U + k5V) (+ k5U): the pair NOT used by the last chunk is
   // one contiguous 72 KiB block for the partial outputs
@@ -97,15 +114,39 @@ __global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) 
   const int nwg = gridDim.x * gridDim.y;
   int lid = blockIdx.x + gridDim.x * blockIdx.y;
   if ((nwg & 7) == 0) lid = (lid & 7) * (nwg >> 3) + (lid >> 3);  // XCD-contiguous logical ids (conv_wino.hip)
-  const int rh = lid & 1, ct = (lid >> 1) % (gridDim.x >> 1), b = (lid >> 1) / (gridDim.x >> 1);
+  const int S = SPLIT ? sp5.S : 1;
+  const int sp = SPLIT ? lid % S : 0;            // the S workgroups of an output tile have consecutive logical ids
+  const int tile_id = SPLIT ? lid / S : lid;     // (b, ct, rh)
+  const int ntile = (gridDim.x / S) >> 1;
+  const int rh = tile_id & 1, ct = (tile_id >> 1) % ntile, b = (tile_id >> 1) / ntile;
   const int r0 = rh * 8;
-  const int nchunk = a.qin >> 1;
+  const int nchunk = (a.qin >> 1) / S;           // this workgroup's share of the chunks: [c0, c0 + nchunk)
+  const int c0 = sp * nchunk;
+  bool fence = false;
+  if (SPLIT) {
+    // which XCD do the tile's workgroups really run on?  (dispatch order puts consecutive logical ids on one; not a guarantee)
+    const unsigned my_xcc = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;
+    const unsigned tag = sp5.epoch << 4;
+    if (tid == 0) __hip_atomic_store(sp5.xcc + lid, tag | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave < 4) {   // the consumers have nothing to do until the first chunk is in LDS
+      for (int p = 0; p < S; ++p) {
+        unsigned v = 0;
+        int n = 0;
+        while (((v = __hip_atomic_load(sp5.xcc + tile_id * S + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~15u) != tag) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++n > (1 << 22)) { v = 0; break; }   // a partner that never started (the grid did not fit): be safe, fence
+        }
+        fence |= ((v & 15u) != my_xcc);
+      }
+      fence = __builtin_amdgcn_readfirstlane(fence);
+    }
+  }
 
   if (wave >= 4) {
     // =========================================== PRODUCERS ===========================================
     const int pw = wave - 4;
     const int quad = pw & 1, colhalf = pw >> 1;  // this wave transforms quad `quad` of every chunk, V columns 3 colhalf .. +2
-    const unsigned u_tile_bytes = (unsigned)nchunk * k5U;
+    const unsigned u_tile_bytes = (unsigned)(nchunk * S) * k5U;
     const __amdgpu_buffer_rsrc_t ru = make_rsrc((const char*)a.w_wino + (size_t)ct * u_tile_bytes, u_tile_bytes);
     const int q2 = a.qin - a.q1;
     const __amdgpu_buffer_rsrc_t rx1 = make_rsrc((const char*)a.src1 + (size_t)b * a.q1 * kQuadBytes, (unsigned)a.q1 * kQuadBytes);
@@ -127,13 +168,13 @@ __global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) 
 #pragma unroll
       for (int g = 0; g < 9; ++g) {
         const int p = pw * 9 + g;
-        dma16(ru, smem + buf * (k5U + k5V) + p * 1024, vw, (c * 36 + p) * 1024);
+        dma16(ru, smem + buf * (k5U + k5V) + p * 1024, vw, ((c0 + c) * 36 + p) * 1024);
       }
     };
     // BOTH waves that transform a quad load it (identical bytes to identical addresses): each then only has to wait for its own
     // DMAs, and the raw tile is a fifth of the chunk's traffic
     auto issue_raw = [&](int c, int buf) {
-      const int q = 2 * c + quad;
+      const int q = 2 * (c0 + c) + quad;
       const bool second = q >= a.q1;
       const int soff = (second ? q - a.q1 : q) * kQuadBytes;
 #pragma unroll
@@ -257,30 +298,108 @@ __global__ __launch_bounds__(512, 1) void conv5x5_wino_kernel(const ConvArgs a) 
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bias4 = *(const f32x4*)(a.bias + Q * 4);
   const int tile = tb * 16 + i16, oty = tile >> 3, otx = tile & 7;
+  f32x4 yv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     f32x4 y = *(const f32x4*)(px + ((0 * 4 + wave) * 4 + e) * 1024 + lane * 16);
 #pragma unroll
     for (int w = 1; w < 4; ++w) y += *(const f32x4*)(px + ((w * 4 + wave) * 4 + e) * 1024 + lane * 16);
-    y += bias4;
+    yv[e] = y;
+  }
+  if (SPLIT) {
+    // deliver this split's partial, count in; the wave that completes the tile adds the S partials in split order
+    float* const mine = sp5.part + (((size_t)tile_id * S + sp) * 4 + wave) * (4 * 64 * 4) + lane * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *(f32x4*)(mine + e * 256) = yv[e];
+    wait_vmcnt<0>();
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    unsigned before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_add(sp5.count + tile_id * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    before = __builtin_amdgcn_readfirstlane(before);
+    if (before != (unsigned)(S - 1)) return;
+    if (lane == 0) __hip_atomic_store(sp5.count + tile_id * 4 + wave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc((const char*)(sp5.part + (size_t)tile_id * S * 4 * (4 * 64 * 4)), (unsigned)S * 4 * 4 * 64 * 16);
+    f32x4 tot[4];
+#pragma unroll 1
+    for (int k = 0; k < S; ++k) {
+      f32x4 pk[4];
+      if (k == sp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = yv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // sc1: never from this CU's vector cache (the bytes were written by another CU a moment ago)
+          pk[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, lane * 16, ((k * 4 + wave) * 4 + e) * 1024, 16));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tot[e] = k == 0 ? pk[e] : tot[e] + pk[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) yv[e] = tot[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f32x4 y = yv[e] + bias4;
     const int P = (r0 + 2 * oty + (e >> 1)) * 16 + 2 * otx + (e & 1);
     float esum = 0.0f;
     emit_quad(a, b, Q, P, y, esum);  // plain / ReLU store, or the backward sweep's epilogues (conv_common.h)
   }
 }
 
+// library-owned scratch of the split launches (partials, counters, XCD words), grown on demand
+static struct Split5State {
+  float* part = nullptr;
+  size_t part_floats = 0;
+  unsigned* words = nullptr;   // [count: kTiles x 4 | xcc: kWgs]
+  unsigned epoch = 0;
+} g_split5;
+constexpr int kSplit5Tiles = 256, kSplit5Wgs = 256;
+
 // returns 1 if the layer has no F(2x2,5x5) form here (the caller then runs the direct kernel)
 int launch_wino5(const ConvArgs& a, hipStream_t stream) {
   if (a.combine == 1 || a.skip || (a.q1 & 1) || (a.qin & 1)) return 1;  // (no Runge-Kutta stage combine on a 5x5 layer)
   static bool attr_set = false;
   if (!attr_set) {
-    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv5x5_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv5x5_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv5x5_wino_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv5x5_wino_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ODEHIP_CHECK_HIP(hipFuncSetAttribute((const void*)conv5x5_wino_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  Split5 sp5 = {1, nullptr, nullptr, nullptr, 0u};
+  const int nwg1 = (a.qout / 8) * 2 * a.batch, nchunk = a.qin >> 1;
+  // split the chunk chain while ALL workgroups still fit the chip at once (they wait for each other's XCD word: every one of them
+  // must be resident) and a share is at least two chunks; ODEHIP_WINO5_SPLIT=0 switches it off (A/B)
+  static const int split_max = [] { const char* e = getenv("ODEHIP_WINO5_SPLIT"); return e ? atoi(e) : 8; }();
+  int S = 1;
+  for (int k = 8; k >= 2; k >>= 1)
+    if (k <= split_max && nwg1 * k <= kSplit5Wgs && nchunk % k == 0 && nchunk / k >= 2 && !(a.debug & (256 | 512 | 1024 | 2048))) { S = k; break; }
+  if (S > 1) {
+    Split5State& G = g_split5;
+    const size_t need = (size_t)nwg1 * S * 4 * 4 * 64 * 4;
+    if (!G.words) {
+      ODEHIP_CHECK_HIP(hipMalloc((void**)&G.words, (kSplit5Tiles * 4 + kSplit5Wgs) * sizeof(unsigned)));
+      ODEHIP_CHECK_HIP(hipMemset(G.words, 0, (kSplit5Tiles * 4 + kSplit5Wgs) * sizeof(unsigned)));
+    }
+    if (G.part_floats < need) {   // (rare, synchronous: a launch in flight may still use the old buffer)
+      ODEHIP_CHECK_HIP(hipStreamSynchronize(stream));
+      if (G.part) (void)hipFree(G.part);
+      G.part = nullptr;
+      G.part_floats = 0;
+      ODEHIP_CHECK_HIP(hipMalloc((void**)&G.part, need * sizeof(float)));
+      G.part_floats = need;
+    }
+    G.epoch = (G.epoch + 1) & 0x0fffffffu;
+    if (G.epoch == 0) G.epoch = 1;
+    sp5 = Split5{S, G.part, G.words, G.words + kSplit5Tiles * 4, G.epoch};
+    const dim3 grid((a.qout / 8) * 2 * S, a.batch);
+    hipLaunchKernelGGL((conv5x5_wino_kernel<false, true>), grid, dim3(512), k5Lds, stream, a, sp5);
+    ODEHIP_CHECK_HIP(hipGetLastError());
+    return ODEHIP_OK;
+  }
   const dim3 grid((a.qout / 8) * 2, a.batch);
-  if (a.debug & (256 | 512 | 1024 | 2048)) hipLaunchKernelGGL(conv5x5_wino_kernel<true>, grid, dim3(512), k5Lds, stream, a);
-  else hipLaunchKernelGGL(conv5x5_wino_kernel<false>, grid, dim3(512), k5Lds, stream, a);
+  if (a.debug & (256 | 512 | 1024 | 2048)) hipLaunchKernelGGL((conv5x5_wino_kernel<true, false>), grid, dim3(512), k5Lds, stream, a, sp5);
+  else hipLaunchKernelGGL((conv5x5_wino_kernel<false, false>), grid, dim3(512), k5Lds, stream, a, sp5);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;
 }

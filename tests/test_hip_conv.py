@@ -107,11 +107,14 @@ def test_winograd_conv_matches_torch(cuda, b, cin, cout, relu):
 
 
 @pytest.mark.parametrize("b,cin1,cin2,cout,relu", [(3, 64, 64, 128, False), (2, 64, 64, 64, True), (1, 8, 0, 32, False),
-                                                   (5, 32, 32, 64, False), (2, 128, 128, 256, False), (70, 64, 64, 128, False)])
+                                                   (5, 32, 32, 64, False), (2, 128, 128, 256, False), (70, 64, 64, 128, False),
+                                                   (4, 64, 64, 128, False), (4, 64, 64, 64, True), (16, 64, 64, 64, False), (9, 64, 64, 128, False)])
 def test_winograd5_conv_matches_torch(cuda, b, cin1, cin2, cout, relu):
     """Winograd F(2x2,5x5) kernel (csrc/conv_wino5.hip; the ConvGRU's convolutions, two sources = torch.cat(x, h) without a copy):
     fp32 arithmetic, reassociated through the 6-point transforms: 2.6e-6 rel-L2 per layer on the CPU model of it
-    (tools/experiments/winograd_f25_error.py); tolerance 1e-5 against torch's CPU conv2d, and the input-gradient form."""
+    (tools/experiments/winograd_f25_error.py); tolerance 1e-5 against torch's CPU conv2d, and the input-gradient form.
+    Round 4: small batches SPLIT the chunk chain over 2 / 4 / 8 workgroups per output tile (the reference's batch 4: 8 and 8; the cases
+    here reach every split count and the unsplit kernel); the partials are added in a fixed order: a second launch is bitwise equal."""
     from ode_rl_amd import hip_ops
     g = torch.Generator().manual_seed(b * 131 + cin1 + cout)
     cin = cin1 + cin2
@@ -130,6 +133,10 @@ def test_winograd5_conv_matches_torch(cuda, b, cin1, cin2, cout, relu):
     assert rel_l2(direct, ref) <= 2e-6
     assert not torch.equal(out, direct)          # the Winograd kernel ran (it is not bit-identical to the direct one)
     assert rel_l2(out, ref) <= 1e-5
+    for _ in range(3):                           # deterministic (also across the split launches' last-arriver reduction)
+        again = hip_ops.q4_to_nchw(hip_ops.conv_q4(src1, hip_ops.pack_conv_weight(wd), bias.to(cuda), cout, 5, src2=src2, relu=relu,
+                                                   w_wino=hip_ops.pack_conv_weight_winograd5(wd)))
+        assert torch.equal(again, out)
     if cin % 32 != 0 or b > 8:
         return
     gy = torch.randn(b, cout, 16, 16, generator=g)
