@@ -57,6 +57,7 @@ class PersistScope {
   ConvRecorder rec_ = {nullptr, 0, 0};
   bool active_ = false;
   bool small_ = false;
+  bool eval_walk_small_only_ = false;   // ODEHIP_EVAL_WALK unset: only batches the sixteen-workgroup walk takes
   bool eval_walk_ = false;   // a small scope that runs on the trajectory walks (ODEHIP_EVAL_WALK=1): library-owned flags, volatile table
   bool adaptive_ = false;
   bool volatile_ = false;

@@ -259,8 +259,12 @@ int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, i
     // backward) as ONE launch of the TRAJECTORY walks -- wino_persist_kernel, or the sixteen-workgroup walk up to batch 16 -- instead
     // of the round-2 single-evaluation kernel below (9.5 us per layer against 7.5 / 3.3): the table goes up through the volatile
     // ring, the flags live in a library-owned area zeroed per launch.  Like the small launches: no NaN guard, errors are reported late.
-    static const bool eval_walk_on = [] { const char* e = getenv("ODEHIP_EVAL_WALK"); return e && e[0] == '1'; }();
-    if (small && eval_walk_on) {
+    // Round 4: ON for batches up to 16 (the sixteen-workgroup walk: the reference's batch 4 trains 5.16 -> 4.92 ms per step with it),
+    // off above (B = 64: the cell loop 2.81 -> 2.93 ms) unless ODEHIP_EVAL_WALK=1 forces it; ODEHIP_EVAL_WALK=0 switches it off.
+    // The batch is only known in finish(): a scope that turns out too large replays its rows as ordinary launches there.
+    static const int eval_walk_env = [] { const char* e = getenv("ODEHIP_EVAL_WALK"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    eval_walk_small_only_ = eval_walk_env < 0;
+    if (small && eval_walk_env != 0) {
       small_ = false;
       eval_walk_ = true;
       volatile_ = true;
@@ -310,7 +314,8 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
     if (g_conv_recorder == &rec_) g_conv_recorder = nullptr;
     if (!active_) return ODEHIP_OK;
     active_ = false;
-    if (eval_walk_ && !sync) {   // the library's flag area (grown synchronously, rarely)
+    const bool eval_skip = eval_walk_ && eval_walk_small_only_ && (batch > 16 || !walk16_on());   // default: small batches only
+    if (eval_walk_ && !sync && !eval_skip) {   // the library's flag area (grown synchronously, rarely)
       PersistState& P = g_persist;
       if (batch > P.eval_batch_cap) {
         bool ok = hipStreamSynchronize(stream) == hipSuccess;
@@ -325,6 +330,7 @@ int PersistScope::finish(const float* hbuf, const float* hdev, float* out_nchw, 
       sync_is_zero = false;
     }
     bool all_ok = rec_.count > 0 && !(eval_walk_ && !sync), wide = false, adaptive = adaptive_;
+    if (eval_skip) all_ok = false;
     for (int i = 0; i < rec_.count && all_ok; ++i) {
       const int kind = persist_layer_kind(rec_.items[i]);
       all_ok = kind != 0;
