@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 10 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 11 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -413,6 +413,14 @@ int odehip_warp_composite_backward(const float* pred_outputs, const float* start
                                    const float* grid_y, const float* grad_pred_x, const float* grad_warped, const float* grad_masks,
                                    int batch, int n_times, int channels, int height, int width, float* grad_pred_outputs,
                                    float* grad_start_image, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) of VidODE's flow decoder (models/VidODE.py:34, applied per
+ * predicted frame by get_flowmaps :143-158) on `planes` = N * C images of (height, width) -> (2 height, 2 width), ATen's arithmetic
+ * (source index max(0, (dst + 0.5) / 2 - 0.5), the four-point blend in its order of operations).  HBM-bound data movement: torch's
+ * own kernel runs it at 20 GB/s on this stack (4.2 ms per call, 85 % of a VidODE forward at batch 64).  width must be even.
+ * Backward: the transpose as a gather (deterministic). */
+int odehip_upsample2x_bilinear(const float* in, float* out, long long planes, int height, int width, void* stream);
+int odehip_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, long long planes, int height, int width, void* stream);
 
 /* ---- the conv encoder / decoder either side of the path (models/ODEConvGRU.py:101-118 Encoder, :121-140 Decoder; n_downs = 2) --
  * Each is ONE fused launch: the 32x32 intermediate stays in LDS, the 16 -> out_ch and in_ch -> 32 layers run on the fp32 MFMA.

@@ -172,6 +172,25 @@ def warp_composite(pred_outputs, start_image, grid_x, grid_y):
     return hip_ops.warp_composite(pred_outputs, start_image, grid_x, grid_y)
 
 
+class _Upsample2xFn(torch.autograd.Function):
+    """Bilinear x2 upsampling (csrc/upsample.hip): linear, so the backward needs nothing saved."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return hip_ops.upsample2x(x.detach())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return hip_ops.upsample2x_backward(g)
+
+
+def upsample2x(x):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _Upsample2xFn.apply(x)
+    return hip_ops.upsample2x(x)
+
+
 class _AdjointOdeint(torch.autograd.Function):
     """torchdiffeq.odeint_adjoint: forward without a graph, backward by integrating the adjoint ODE backwards."""
 

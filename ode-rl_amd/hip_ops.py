@@ -1117,6 +1117,27 @@ def warp_composite_backward(pred_outputs, start_image, warped, grid_x, grid_y, g
     return g_po, g_start
 
 
+def upsample2x(x):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) of an (..., H, W) fp32 device tensor (csrc/upsample.hip)."""
+    require_device_tensor(x, "input")
+    if x.dim() < 2 or x.shape[-1] % 2:
+        raise ValueError(f"upsample2x: needs (..., H, W) with an even W, got {tuple(x.shape)}")
+    x = x.contiguous()
+    h, w = x.shape[-2:]
+    out = torch.empty(tuple(x.shape[:-2]) + (2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().odehip_upsample2x_bilinear(_ptr(x), _ptr(out), x.numel() // (h * w), h, w, _stream()))
+    return out
+
+
+def upsample2x_backward(g):
+    require_device_tensor(g, "gradient")
+    g = g.contiguous()
+    h2, w2 = g.shape[-2:]
+    gin = torch.empty(tuple(g.shape[:-2]) + (h2 // 2, w2 // 2), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.load().odehip_upsample2x_bilinear_backward(_ptr(g), _ptr(gin), gin.numel() // ((h2 // 2) * (w2 // 2)), h2 // 2, w2 // 2, _stream()))
+    return gin
+
+
 # ---- the conv encoder / decoder either side of the path (models/ODEConvGRU.py:101-140), one fused launch each ------------------
 _codec_packs = {}   # id(module) -> (weakref to module, stamp, pack tensor)
 
