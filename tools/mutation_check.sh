@@ -26,8 +26,12 @@ SED[wgrad_wino5_bt]='s/  out\[0\] = w5_fma2(4.0f, in\[0\], w5_fma2(-5.0f, in\[2\
 SED[codec_bwd_dec_tap]='s/          const int pa = (ky \& 1) ^ 1, ta = ky >> 1, pb = (kx \& 1) ^ 1, tb = kx >> 1;/          const int pa = (ky \& 1) ^ 1, ta = ky >> 1, pb = (kx \& 1), tb = kx >> 1;/'   # decoder backward: column parity of the second layer'"'"'s weights
 SED[codec_bwd_enc_dx]='s/        const int dx = kx == 0 ? 1 : 0;/        const int dx = kx == 2 ? 1 : 0;/'   # encoder backward: which odd-column tap reads the next source column
 SED[codec_bwd_dw1_centre]='s/        const float\* const bp = gm + ((2 \* iy + ky) \* kMW + 8 \* kq + kx) \* kMPix + nn;/        const float* const bp = gm + ((2 * iy + ky) * kMW + 8 * kq + kx + 1) * kMPix + nn;/'   # decoder backward: dW1 operand shifted by one column
+# ---- round 4: the flow decoder's upsampling, the split 5x5 launches, the seal of an asynchronous solve
+SED[upsample_src_index]='s/  float s = 0.5f \* ((float)dst + 0.5f) - 0.5f;/  float s = 0.5f * ((float)dst + 0.5f) - 0.45f;/'           # bilinear x2: source index off by 0.05 px
+SED[split5_drop_partial]='s/      for (int e = 0; e < 4; ++e) tot\[e\] = k == 0 ? pk\[e\] : tot\[e\] + pk\[e\];/      for (int e = 0; e < 4; ++e) tot[e] = k <= 1 ? pk[e] : tot[e] + pk[e];/'   # split 5x5 conv: the first split'"'"'s partial is dropped
+SED[seal_no_nan]='s/  for (long long i = (long long)blockIdx.x \* 256 + threadIdx.x; i < n; i += (long long)gridDim.x \* 256) o\[i\] = nan;/  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = 0.0f;/'   # sealed async solve: unreached frames zero instead of NaN
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd"
+TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd tests/test_hip_vidode.py::test_upsample2x_matches_torch tests/test_hip_backward.py::test_async_dopri5_forward_matches_the_synchronous_one"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
