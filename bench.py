@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                   box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -56,7 +57,8 @@ def profiled_traffic():
     except OSError as e:
         return None, f"kernel sources unreadable: {e!r}"
     why = "no PMC summary under profiles/"
-    for tag in ("r03", "r02", "r01"):
+    tags = sorted((os.path.basename(p)[:3] for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_rocprof_summary.json"))), reverse=True)
+    for tag in tags:   # newest round first
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")) as fh:
                 notes = json.load(fh)["notes"]
@@ -90,6 +92,9 @@ def parse():
     p.add_argument("--side-stream", action="store_true", help="diagnostic: run the timed region on a non-default stream")
     p.add_argument("--adjoint-norm", default="seminorm", choices=["seminorm", "mixed"],
                    help="dopri5 adjoint: seminorm, or torchdiffeq's default mixed norm (parameter block steers the steps)")
+    p.add_argument("--max-accept", type=int, default=0,
+                   help="dopri5 adjoint: accepted backward steps whose activations are kept (default: what fits 32 GiB; the mixed norm at "
+                        "rtol 1e-5 needs several hundred at B=64: 280 MiB each)")
     p.add_argument("--rtol", type=float, default=None, help="dopri5 tolerances (default: DiffEqSolver's 1e-4 / 1e-5)")
     p.add_argument("--atol", type=float, default=None)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -401,7 +406,8 @@ def main():
         f.zero_grad()   # torch 2 default (set_to_none=True), what the reference's `optimizer.zero_grad()` (train_test.py:176) does today
         if a.adjoint:
             o = ode_rl_amd.odeint_adjoint(f, zz, t, rtol=solver.odeint_rtol, atol=solver.odeint_atol, method=a.method,
-                                          adjoint_options={"norm": a.adjoint_norm} if a.method == "dopri5" else None)
+                                          adjoint_options=({"norm": a.adjoint_norm, **({"max_accept": a.max_accept} if a.max_accept else {})}
+                                                           if a.method == "dopri5" else None))
         else:
             o = solver(zz, t)
         o.backward(gout)

@@ -24,7 +24,7 @@ run dopri5_train --method dopri5 --train --no-cpu-baseline --no-model
 # Both adjoint norms: the seminorm, and torchdiffeq's default MIXED norm (every parameter tensor's error ratio steers the steps: an
 # order of magnitude more backward steps by construction, in torchdiffeq as here)
 run config2_adjoint --method dopri5 --train --adjoint --rtol 1e-5 --no-cpu-baseline --steps 20 --no-model
-run config2_adjoint_mixed --method dopri5 --train --adjoint --adjoint-norm mixed --rtol 1e-5 --no-cpu-baseline --steps 3 --warmup 1 --no-model --no-config0
+run config2_adjoint_mixed --method dopri5 --train --adjoint --adjoint-norm mixed --max-accept 700 --rtol 1e-5 --no-cpu-baseline --steps 3 --warmup 1 --no-model --no-config0
 run config2_adjoint_atol1e-6 --method dopri5 --train --adjoint --rtol 1e-5 --atol 1e-6 --no-cpu-baseline --steps 20 --no-model --no-config0
 run config3_vidode_fwd --shape V --no-cpu-baseline --no-config0 --no-model
 run config3_vidode_train --shape V --train --no-cpu-baseline --no-model
