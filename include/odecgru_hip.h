@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ODEHIP_ABI_VERSION 11 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
+#define ODEHIP_ABI_VERSION 12 /* == odehip_version(); bumped whenever a struct layout or a signature below changes */
 #define ODEHIP_MAX_LAYERS 8
 #define ODEHIP_MAX_STAGES 7
 
@@ -421,6 +421,23 @@ int odehip_warp_composite_backward(const float* pred_outputs, const float* start
  * Backward: the transpose as a gather (deterministic). */
 int odehip_upsample2x_bilinear(const float* in, float* out, long long planes, int height, int width, void* stream);
 int odehip_upsample2x_bilinear_backward(const float* grad_out, float* grad_in, long long planes, int height, int width, void* stream);
+
+/* BatchNorm2d -> ReLU (-> that upsampling) of the same decoder (models/VidODE.py:35-36) as one pass over the convolution's output
+ * x (batch, channels, height, width) NCHW fp32; width % 4 == 0.  training != 0: the statistics of THIS call (biased variance for the
+ * normalisation; running_mean / running_var, if given, updated with `momentum` and the unbiased variance, as nn.BatchNorm2d does);
+ * else the running statistics.  weight / bias may be NULL (affine=False).  out = relu(bn(x)), upsampled x2 (-> 2 height x 2 width) when
+ * upsample != 0.  mean_out, invstd_out, scale_out, shift_out [channels]: what the backward needs (scale = weight * invstd,
+ * shift = bias - mean * scale).  workspace: odehip_bn_workspace_bytes(channels) (forward), + 2 * channels floats (backward).
+ * Backward: grad_out has out's shape; g_pre (x's shape) is scratch the caller provides; grad_x, grad_weight, grad_bias are written.
+ * Every reduction has a fixed order: bitwise reproducible. */
+size_t odehip_bn_workspace_bytes(int channels);
+int odehip_bn_relu_up2x_forward(const float* x, int batch, int channels, int height, int width, const float* weight, const float* bias,
+                                float* running_mean, float* running_var, int training, float momentum, float eps, int upsample, float* out,
+                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int odehip_bn_relu_up2x_backward(const float* grad_out, const float* x, int batch, int channels, int height, int width, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, int training, int upsample, float* grad_x,
+                                 float* grad_weight, float* grad_bias, float* g_pre, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the conv encoder / decoder either side of the path (models/ODEConvGRU.py:101-118 Encoder, :121-140 Decoder; n_downs = 2) --
  * Each is ONE fused launch: the 32x32 intermediate stays in LDS, the 16 -> out_ch and in_ch -> 32 layers run on the fp32 MFMA.

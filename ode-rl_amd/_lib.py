@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODEHIP_LIB") or os.path.join(_HERE, "lib", "libodecgru_hip.so")  # env override: A/B builds
 
-ABI_VERSION = 11   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
+ABI_VERSION = 12   # == odehip_version() of the library these ctypes structs were written against (ODEHIP_ABI_VERSION in the header)
 MAX_LAYERS = 8
 MAX_STAGES = 7
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
@@ -122,6 +122,11 @@ SIGNATURES = {
     "odehip_upsample2x_bilinear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "odehip_upsample2x_bilinear_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                                             ctypes.c_void_p]),
+    "odehip_bn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "odehip_bn_relu_up2x_forward": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_float,
+                                                   ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]),
+    "odehip_bn_relu_up2x_backward": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 +
+                                     [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
     "odehip_warp_composite": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 4),
     "odehip_warp_composite_backward": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3),
     "odehip_winograd5_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

@@ -191,6 +191,33 @@ def upsample2x(x):
     return hip_ops.upsample2x(x)
 
 
+class _BnReluUpFn(torch.autograd.Function):
+    """BatchNorm2d -> ReLU (-> bilinear x2 upsampling) in one pass (csrc/bn_relu_up.hip): VidODE's flow decoder, models/VidODE.py:34-36."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, upsample):
+        out, saved = hip_ops.bn_relu_up_forward(x.detach(), bn, upsample)
+        ctx.saved_stats, ctx.upsample = saved, upsample
+        ctx.affine = weight is not None
+        ctx.save_for_backward(x.detach())
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gx, gw, gb = hip_ops.bn_relu_up_backward(g, x, ctx.saved_stats, ctx.upsample)
+        return gx, (gw if ctx.affine else None), (gb if ctx.affine else None), None, None
+
+
+def bn_relu_up(x, bn, upsample):
+    """relu(bn(x)), upsampled x2 if `upsample`; bn: nn.BatchNorm2d (train() or eval() as the module says; running statistics and
+    num_batches_tracked updated as the module itself would)."""
+    if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)):
+        return _BnReluUpFn.apply(x, bn.weight, bn.bias, bn, bool(upsample))
+    return hip_ops.bn_relu_up_forward(x, bn, upsample)[0]
+
+
 class _AdjointOdeint(torch.autograd.Function):
     """torchdiffeq.odeint_adjoint: forward without a graph, backward by integrating the adjoint ODE backwards."""
 

@@ -1138,6 +1138,49 @@ def upsample2x_backward(g):
     return gin
 
 
+def bn_relu_up_forward(x, bn, upsample):
+    """relu(bn(x)) [upsampled x2] in one pass (csrc/bn_relu_up.hip); bn: an nn.BatchNorm2d (its running statistics are updated in
+    train() mode exactly as the module would).  Returns (out, saved) with saved = (mean, invstd, scale, shift) for the backward."""
+    require_device_tensor(x, "input")
+    if x.dim() != 4 or x.shape[3] % 4:
+        raise ValueError(f"bn_relu_up: needs (N, C, H, W) with W % 4 == 0, got {tuple(x.shape)}")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    dev = x.device
+    training = bn.training or bn.running_mean is None
+    stats = torch.empty((4, c), dtype=torch.float32, device=dev)
+    out = torch.empty((n, c, 2 * h, 2 * w) if upsample else (n, c, h, w), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nws = lib.odehip_bn_workspace_bytes(c)
+    ws = workspace(("bn", c), nws + 8 * c, dev)
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    _lib.check(lib.odehip_bn_relu_up2x_forward(_ptr(x), n, c, h, w, _ptr(bn.weight), _ptr(bn.bias),
+                                               _ptr(bn.running_mean) if (bn.track_running_stats and bn.running_mean is not None) else None,
+                                               _ptr(bn.running_var) if (bn.track_running_stats and bn.running_var is not None) else None,
+                                               int(training), float(bn.momentum), float(bn.eps), int(bool(upsample)), _ptr(out),
+                                               _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel(), _stream()))
+    return out, (stats, training)
+
+
+def bn_relu_up_backward(grad_out, x, saved, upsample):
+    stats, training = saved
+    require_device_tensor(grad_out, "gradient")
+    grad_out, x = grad_out.contiguous(), x.contiguous()
+    n, c, h, w = x.shape
+    dev = x.device
+    lib = _lib.load()
+    gx = torch.empty_like(x)
+    g_pre = torch.empty_like(x)
+    gw = torch.empty(c, dtype=torch.float32, device=dev)
+    gb = torch.empty(c, dtype=torch.float32, device=dev)
+    ws = workspace(("bn", c), lib.odehip_bn_workspace_bytes(c) + 8 * c, dev)
+    _lib.check(lib.odehip_bn_relu_up2x_backward(_ptr(grad_out), _ptr(x), n, c, h, w, _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]),
+                                                int(training), int(bool(upsample)), _ptr(gx), _ptr(gw), _ptr(gb), _ptr(g_pre), _ptr(ws), ws.numel(),
+                                                _stream()))
+    return gx, gw, gb
+
+
 # ---- the conv encoder / decoder either side of the path (models/ODEConvGRU.py:101-140), one fused launch each ------------------
 _codec_packs = {}   # id(module) -> (weakref to module, stamp, pack tensor)
 

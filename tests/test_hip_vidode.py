@@ -176,3 +176,94 @@ def test_upsample2x_matches_torch(cuda, shape):
     with torch.no_grad():   # the module the model uses; an upsampled constant is that constant
         assert torch.equal(Upsample2x()(x.to(cuda)), out.detach())
         assert torch.equal(upsample2x(torch.full(shape, 0.75, device=cuda)), torch.full(ref.shape, 0.75, device=cuda))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("upsample", [True, False])
+@pytest.mark.parametrize("shape", [(3, 8, 4, 8), (5, 128, 32, 32), (2, 64, 64, 64)])
+def test_bn_relu_up_matches_torch(cuda, shape, upsample, training):
+    """Round 4: BatchNorm2d -> ReLU (-> the next block's bilinear x2 upsampling) of VidODE's flow decoder (models/VidODE.py:34-36) as one
+    HIP pass (csrc/bn_relu_up.hip) against the three torch modules in fp64 on the CPU: output <= 2e-6, gradients of x / gamma / beta
+    <= 2e-5 (a pre-activation within fp32 round-off of 0 may take the other ReLU branch: inputs are kept off the kink), the module's
+    running statistics and num_batches_tracked as nn.BatchNorm2d leaves them (<= 1e-6), bitwise reproducible."""
+    import copy
+    import torch.nn.functional as F
+    from ode_rl_amd.autograd import bn_relu_up
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(n * 7 + c + (2 if upsample else 0) + (1 if training else 0))
+    x = torch.randn(*shape, generator=g) * 1.5 + 0.3
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    bn.train(training)
+    ref_bn = copy.deepcopy(bn).double()
+    xr = x.double().requires_grad_(True)
+    pre = ref_bn(xr)
+    # keep the comparison off the ReLU kink: nudge the few inputs whose pre-activation is within 1e-4 of 0 (in the fp64 reference)
+    with torch.no_grad():
+        near = pre.abs() < 1e-4
+    if bool(near.any()):
+        x = x + near.float() * 0.01
+        ref_bn = copy.deepcopy(bn).double()
+        xr = x.double().requires_grad_(True)
+        pre = ref_bn(xr)
+    ref = torch.relu(pre)
+    if upsample:
+        ref = F.interpolate(ref, scale_factor=2, mode="bilinear", align_corners=False)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout.double())
+    bnd = copy.deepcopy(bn).to(cuda)
+    xd = x.to(cuda).requires_grad_(True)
+    out = bn_relu_up(xd, bnd, upsample)
+    assert out.shape == ref.shape and record(f"bn_relu_up.fwd.{shape}.{upsample}.{training}", rel_l2(out, ref)) <= 2e-6
+    out.backward(gout.to(cuda))
+    assert record(f"bn_relu_up.gx.{shape}.{upsample}.{training}", rel_l2(xd.grad, xr.grad)) <= 2e-5
+    assert rel_l2(bnd.weight.grad, ref_bn.weight.grad) <= 2e-5 and rel_l2(bnd.bias.grad, ref_bn.bias.grad) <= 2e-5
+    assert rel_l2(bnd.running_mean, ref_bn.running_mean) <= 1e-6 and rel_l2(bnd.running_var, ref_bn.running_var) <= 1e-6
+    assert int(bnd.num_batches_tracked) == int(ref_bn.num_batches_tracked) == (1 if training else 0)
+    g1 = (xd.grad.clone(), bnd.weight.grad.clone(), bnd.bias.grad.clone(), out.detach().clone())
+    bnd2 = copy.deepcopy(bn).to(cuda)
+    xd2 = x.to(cuda).requires_grad_(True)
+    out2 = bn_relu_up(xd2, bnd2, upsample)
+    out2.backward(gout.to(cuda))
+    assert torch.equal(out2, g1[3]) and torch.equal(xd2.grad, g1[0]) and torch.equal(bnd2.weight.grad, g1[1]) and torch.equal(bnd2.bias.grad, g1[2])
+    with torch.no_grad():   # without a graph: the same numbers
+        bnd3 = copy.deepcopy(bn).to(cuda)
+        assert torch.equal(bn_relu_up(x.to(cuda), bnd3, upsample), g1[3])
+
+
+@pytest.mark.gpu
+def test_flow_decoder_fused_equals_module_by_module(cuda):
+    """The Decoder's fused forward (convolution -> one HIP pass for BatchNorm + ReLU + the next upsampling) against the same modules
+    called one by one (ODEHIP_FLOW_FUSED=0: MIOpen's BatchNorm, torch's ReLU, csrc/upsample.hip): output, every parameter gradient and
+    the BatchNorm buffers <= 1e-5, in train() and eval() mode."""
+    import copy
+    import os
+    from ode_rl_amd.models.VidODE import Decoder
+    torch.manual_seed(3)
+    dec = Decoder(256, 4, 2).to(cuda)
+    x = torch.randn(6, 256, 16, 16, device=cuda)
+    gout = torch.randn(6, 4, 64, 64, device=cuda)
+    for training in (True, False):
+        res = []
+        for fused in ("1", "0"):
+            d = copy.deepcopy(dec).train(training)
+            os.environ["ODEHIP_FLOW_FUSED"] = fused
+            try:
+                xi = x.clone().requires_grad_(True)
+                out = d(xi)
+                out.backward(gout)
+            finally:
+                os.environ.pop("ODEHIP_FLOW_FUSED")
+            res.append((out.detach(), xi.grad, [p.grad for p in d.parameters()], [b.clone() for b in d.buffers()]))
+        a, b = res
+        assert record(f"flow_decoder.fused.out.{training}", rel_l2(a[0], b[0])) <= 1e-5
+        assert record(f"flow_decoder.fused.gx.{training}", rel_l2(a[1], b[1])) <= 1e-4
+        for u, v in zip(a[2], b[2]):
+            assert rel_l2(u, v) <= 1e-4
+        for u, v in zip(a[3], b[3]):
+            assert rel_l2(u.float(), v.float()) <= 1e-5

@@ -5,7 +5,8 @@ only now and then:
     counters reset by the previous launch), every output compared BITWISE with the first run's;
   * the encoder loop's Euler steps on the sixteen-workgroup walk (library-owned flag area, zeroed per launch): whole training steps of
     the ODEConvGRU model at the reference's batch 4 (configs.yaml:7), loss / gradients of step k compared bitwise with a replay of step
-    k from the same parameters, allocated memory constant, no persistent-launch give-up.
+    k from the same parameters, allocated memory constant over the last quarter of the run (before that the dopri5 workspaces follow
+    the accepted-step count, which grows as the dynamics train), no persistent-launch give-up.
   python tools/soak_small_batch.py [--iters 2000] [--steps 200]"""
 import argparse
 import copy
@@ -84,14 +85,14 @@ def main():
             losses.append(float(l2))
         else:
             losses.append(float(train_batch(m, batch, optim)[2]))
-        if step == 20:
-            mem0 = torch.cuda.memory_allocated()
+        if step == a.steps - a.steps // 4:   # the last quarter must not grow (earlier the dopri5 workspaces follow the growing step count:
+            mem0 = torch.cuda.memory_allocated()   # more accepted steps -> more saved slots, up to 64)
     torch.cuda.synchronize()
     code = lib.odehip_persistent_error(0)
     print(f"training at batch 4: {a.steps} steps ({replays} replayed bitwise), loss {losses[0]:.5f} -> {losses[-1]:.5f}, "
-          f"{lib.odehip_persistent_trajectory_launches() - n0} persistent launches, allocated {mem0} -> {torch.cuda.memory_allocated()} bytes, "
+          f"{lib.odehip_persistent_trajectory_launches() - n0} persistent launches, allocated {mem0} bytes at 3/4 of the run -> {torch.cuda.memory_allocated()} at its end, "
           f"{time.perf_counter() - t0:.1f} s, sticky error word {code}")
-    assert code == 0 and all(x == x for x in losses) and losses[-1] < losses[0] and torch.cuda.memory_allocated() <= mem0 * 1.01
+    assert code == 0 and all(x == x for x in losses) and losses[-1] < losses[0] and torch.cuda.memory_allocated() <= mem0 * 1.01 and torch.cuda.memory_allocated() < (4 << 30)
 
 
 if __name__ == "__main__":
