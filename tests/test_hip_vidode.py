@@ -263,7 +263,14 @@ def test_flow_decoder_fused_equals_module_by_module(cuda):
         a, b = res
         assert record(f"flow_decoder.fused.out.{training}", rel_l2(a[0], b[0])) <= 1e-5
         assert record(f"flow_decoder.fused.gx.{training}", rel_l2(a[1], b[1])) <= 1e-4
-        for u, v in zip(a[2], b[2]):
-            assert rel_l2(u, v) <= 1e-4
+        names = [n for n, _ in dec.named_parameters()]
+        for n, u, v in zip(names, a[2], b[2]):
+            if training and n in ("cnn_decoder.1.bias", "cnn_decoder.5.bias"):
+                # the bias of a convolution in front of a batch-statistics BatchNorm has NO gradient (the mean is subtracted again):
+                # both paths produce round-off noise around 0, eight orders below the weight gradients
+                scale = float(a[2][names.index(n.replace("bias", "weight"))].abs().max())
+                assert float(u.abs().max()) <= 1e-4 * scale and float(v.abs().max()) <= 1e-4 * scale
+            else:
+                assert rel_l2(u, v) <= 1e-4, n
         for u, v in zip(a[3], b[3]):
             assert rel_l2(u.float(), v.float()) <= 1e-5
