@@ -72,20 +72,14 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     const long long r = i / W;
     const int y = (int)(r % H);
     const long long pl = r / H;
-    float wy[4], wx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int oy = 2 * y - 1 + k, ox = 2 * x - 1 + k;
-      wy[k] = wx[k] = 0.0f;
-      if (oy >= 0 && oy < H2) {
-        const Src s = src_of(oy, H);
-        wy[k] = (s.i0 == y ? s.l0 : 0.0f) + (s.i1 == y ? s.l1 : 0.0f);
-      }
-      if (ox >= 0 && ox < W2) {
-        const Src s = src_of(ox, W);
-        wx[k] = (s.i0 == x ? s.l0 : 0.0f) + (s.i1 == x ? s.l1 : 0.0f);
-      }
-    }
+    // weights of the output rows 2y-1 .. 2y+2 on input row y: {1/4, 3/4, 3/4, 1/4}; at the borders the clamped stencils fold onto the
+    // edge row (y = 0: rows 0, 1, 2 -> {1, 3/4, 1/4}; y = H-1: rows 2H-3 .. 2H-1 -> {1/4, 3/4, 1}) -- exactly what src_of() yields (the
+    // weights are exact binary fractions), without its float -> int conversions per tap
+    float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    if (y == 0) { wy[0] = 0.0f; wy[1] = 1.0f; }
+    if (y == H - 1) { wy[2] = 1.0f; wy[3] = 0.0f; }
+    if (x == 0) { wx[0] = 0.0f; wx[1] = 1.0f; }
+    if (x == W - 1) { wx[2] = 1.0f; wx[3] = 0.0f; }
     float acc = 0.0f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
