@@ -25,12 +25,12 @@ struct UpSrc {
 };
 __device__ __forceinline__ UpSrc up_src_of(int dst, int n) {   // = src_of of upsample.hip (ATen, align_corners = false, scale 1/2)
 #pragma clang fp contract(off)
-  float s = 0.5f * ((float)dst + 0.5f) - 0.5f;
-  s = s < 0.0f ? 0.0f : s;
+  float src = 0.5f * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
   UpSrc r;
-  r.i0 = (int)s;
+  r.i0 = (int)src;
   r.i1 = r.i0 + (r.i0 < n - 1 ? 1 : 0);
-  r.l1 = s - (float)r.i0;
+  r.l1 = src - (float)r.i0;
   r.l0 = 1.0f - r.l1;
   return r;
 }

@@ -30,16 +30,20 @@ SED[codec_bwd_dw1_centre]='s/        const float\* const bp = gm + ((2 \* iy + k
 SED[upsample_src_index]='s/  float s = 0.5f \* ((float)dst + 0.5f) - 0.5f;/  float s = 0.5f * ((float)dst + 0.5f) - 0.45f;/'           # bilinear x2: source index off by 0.05 px
 SED[split5_drop_partial]='s/      for (int e = 0; e < 4; ++e) tot\[e\] = k == 0 ? pk\[e\] : tot\[e\] + pk\[e\];/      for (int e = 0; e < 4; ++e) tot[e] = k <= 1 ? pk[e] : tot[e] + pk[e];/'   # split 5x5 conv: the first split'"'"'s partial is dropped
 SED[seal_no_nan]='s/  for (long long i = (long long)blockIdx.x \* 256 + threadIdx.x; i < n; i += (long long)gridDim.x \* 256) o\[i\] = nan;/  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = 0.0f;/'   # sealed async solve: unreached frames zero instead of NaN
+SED[bn_bwd_mean_term]='s/  m2\[c\] = (float)(b \/ count);/  m2[c] = (float)(a \/ count);/'   # fused BatchNorm backward: the xhat term gets the wrong mean
+SED[bn_running_var_biased]='s/    const double unbiased = count > 1.0 ? var \* count \/ (count - 1.0) : var;/    const double unbiased = var;/'   # running_var updated with the biased variance
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd tests/test_hip_vidode.py::test_upsample2x_matches_torch tests/test_hip_backward.py::test_async_dopri5_forward_matches_the_synchronous_one"
+TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd tests/test_hip_vidode.py::test_upsample2x_matches_torch tests/test_hip_vidode.py::test_bn_relu_up_matches_torch tests/test_hip_backward.py::test_async_dopri5_forward_matches_the_synchronous_one"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
     if [ -n "${MUT_ONLY:-}" ] && [[ ! " $MUT_ONLY " =~ " $m " ]]; then continue; fi
     d=$MUT/$m
     rm -rf "$d"; mkdir -p "$d/ode-rl_amd/csrc" "$d/include"
-    cp "$ROOT"/ode-rl_amd/csrc/*.hip "$ROOT"/ode-rl_amd/csrc/*.h "$ROOT"/ode-rl_amd/csrc/Makefile "$d/ode-rl_amd/csrc/"
-    cp "$ROOT"/include/*.h "$d/include/"
+    # sources AND the unmutated build's objects with their timestamps: make then recompiles only what the mutation touches
+    cp -p "$ROOT"/ode-rl_amd/csrc/*.hip "$ROOT"/ode-rl_amd/csrc/*.h "$ROOT"/ode-rl_amd/csrc/Makefile "$d/ode-rl_amd/csrc/"
+    cp -p "$ROOT"/include/*.h "$d/include/"
+    if [ -d "$ROOT/ode-rl_amd/csrc/build" ]; then mkdir -p "$d/ode-rl_amd/csrc/build"; cp -p "$ROOT"/ode-rl_amd/csrc/build/*.o "$d/ode-rl_amd/csrc/build/"; fi
     sed -i "${SED[$m]}" "$d"/ode-rl_amd/csrc/*.hip "$d"/ode-rl_amd/csrc/*.h
     changed=0
     for f in "$d"/ode-rl_amd/csrc/*.hip "$d"/ode-rl_amd/csrc/*.h; do
@@ -74,5 +78,11 @@ run)
     fi
   done
   exit $bad ;;
-*) echo "usage: $0 build|run" >&2; exit 2 ;;
+baseline)   # the unmutated library alone (starts a fresh summary; the mutants then follow with MUT_ONLY=... run, one lease at a time)
+  out=$ROOT/gpurun_out/mutation_check.txt
+  cd "$ROOT"
+  python -m pytest $TESTS -q > gpurun_out/mut_baseline.log 2>&1; rc=$?
+  echo "unmutated library: pytest rc=$rc ($(tail -1 gpurun_out/mut_baseline.log))" | tee "$out"
+  exit $rc ;;
+*) echo "usage: $0 build|baseline|run" >&2; exit 2 ;;
 esac
