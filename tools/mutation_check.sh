@@ -73,7 +73,7 @@ run)
     grep '^FAILED' gpurun_out/mut_$m.log | sed 's/ - .*//' >> "$out"
     [ $rc -eq 0 ] && { echo "  !! mutant $m SURVIVED" | tee -a "$out"; bad=1; }
     # the mutant must fail on PARITY (an assertion of a test), not because it could not be loaded or crashed
-    if grep -qE "OdeHipError|AttributeError|OSError|Segmentation|core dumped" gpurun_out/mut_$m.log; then
+    if grep -qE "is missing: build it|reports ABI version|cannot open shared object|undefined symbol|AttributeError: .*odehip_|OSError|Segmentation|core dumped" gpurun_out/mut_$m.log; then
       echo "  !! mutant $m failed for the wrong reason (library not loaded / crash): rebuild the mutants" | tee -a "$out"; bad=1
     fi
   done
