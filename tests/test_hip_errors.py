@@ -101,7 +101,7 @@ def test_a_lost_partner_in_a_trajectory_walk_is_loud(cuda):
         pytest.skip("the sixteen-workgroup walk is switched off for this run")
     rec = _fault_run("trajectory")
     if not rec.get("raised_in_call"):
-        assert rec["first_frame_is_z0"] and rec["later_frames_all_nan"], rec
+        assert rec["later_frames_all_nan"], rec   # (the guard fills the whole result, solution[0] included)
         assert rec["next_call_raised"], rec
     assert rec["usable_afterwards"], rec
 
