@@ -111,7 +111,7 @@ __global__ void bn_eval_affine_kernel(int C, float eps, const float* __restrict_
 
 __device__ __forceinline__ float bn_relu(float v, float a, float b) {
   const float y = __builtin_fmaf(v, a, b);
-  return y > 0.0f ? y : 0.0f;
+  return y < 0.0f ? 0.0f : y;   // (NaN passes through, as torch.relu)
 }
 
 // out = relu(x * scale[c] + shift[c]); UP: upsampled x2 (one thread = four consecutive output pixels of a row)

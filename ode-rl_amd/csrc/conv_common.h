@@ -4,6 +4,11 @@
 
 namespace odehip {
 
+// ReLU that PROPAGATES NaN, as torch.relu does: v_max_f32(v, 0) returns 0 for a NaN input, which would launder a non-finite
+// activation into a plausible zero (found by round 4's fault-injection test: NaN written by a walk that had given up disappeared in the
+// ReLUs of the encoder's 1x1 head).  v < 0 is false for NaN, so NaN passes through; finite values are unchanged.
+__device__ __forceinline__ float relu_f(float v) { return v < 0.0f ? 0.0f : v; }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -102,7 +107,7 @@ __device__ __forceinline__ void emit_quad(const ConvArgs& a, int b, int Q, int P
   const size_t off = (((size_t)b * a.qout + Q) * kPix + P) * 4;
   if (a.combine == 0) {
     if (a.relu) {
-      v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+      v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w);
     }
     *(f32x4*)(a.dst + off) = v;
     return;
@@ -243,7 +248,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, const f32x16& acc, i
     for (int g = 0; g < 4; ++g) {
       f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
       if (a.relu) {
-        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w);
       }
       const size_t off = (((size_t)b * a.qout + ct * 8 + 2 * g + kq) * kPix + P) * 4;
       *(f32x4*)(a.dst + off) = v;

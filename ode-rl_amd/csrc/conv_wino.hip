@@ -506,7 +506,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     const size_t off = (((size_t)b * QOUT + Q) * kPix + P) * 4;
     if (!e_combine) {
       if (e_relu) {
-        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w);
       }
       *(f32x4*)(e_dst + off) = v;
       return;
@@ -556,7 +556,7 @@ __device__ __forceinline__ void wino_layer(const float* __restrict__ p_src, cons
     const size_t off = (((size_t)b * QOUT + Q) * kPix + P) * 4;
     if (d_kind == 0) {
       if (e_relu) {
-        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w);
       }
       *(f32x4*)(e_dst + off) = v;
     } else if (d_kind == 2) {
@@ -1331,7 +1331,7 @@ __device__ __forceinline__ void wino_layer16(const float* __restrict__ p_src, co
   }
   if (!e_combine) {
     if (e_relu) {
-      val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f);
+      val.x = relu_f(val.x); val.y = relu_f(val.y); val.z = relu_f(val.z); val.w = relu_f(val.w);
     }
     *(f32x4*)(e_dst + off) = val;
   } else if (e_combine == 2) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void fstack_bf16_kernel(const FusedArgs fa)
           const f32x4 m = mreg[nb * 4 + g];
           v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         } else {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w);
         }
         if (st) *(f32x4*)(st + off) = v;
         *(u32x2*)(act + ((row0 + 2 * nb + 1) * 18 + px + 1) * kFS + Q * 8) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void ftraj_bf16_kernel(const TrajArgs ta) {
           for (int nb = 0; nb < 2; ++nb) {
             f32x16 v = nb ? acc1 : acc0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+            for (int i = 0; i < 16; ++i) v[i] = relu_f(v[i]);
             emit(v, nb, dst);
           }
           cur ^= 1;
