@@ -120,3 +120,29 @@ def test_a_lost_partner_in_a_single_evaluation_walk_is_loud(cuda):
         assert rec["output_has_nan"] and not rec["output_equals_good"], rec
         assert rec["next_call_raised"], rec
     assert rec["usable_afterwards"], rec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["rk4", "euler"])
+def test_a_non_finite_state_is_not_laundered(cuda, method):
+    """torch.relu propagates NaN; v_max_f32(x, 0) returns 0 for it, which would turn a non-finite activation into a plausible zero
+    (round 4: every ReLU of the library is `x < 0 ? 0 : x`).  A NaN in one sample's z0: wherever the oracle's trajectory is NaN the HIP
+    trajectory is NaN too (Winograd tiles may spread it further, never less); the other sample of the batch is untouched, bit for bit."""
+    import ode_rl_amd
+    from oracle import reference_modules as rm
+    from oracle import torchdiffeq_ref
+    torch.manual_seed(2)
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    ws, bs = rm.split_convnet_state({k: v.detach().clone() for k, v in f.state_dict().items()}, "gradient_net.")
+    z0 = torch.randn(2, 64, 16, 16) * 0.5
+    clean = z0.clone()
+    z0[0, 5, 7, 9] = float("nan")
+    t = torch.tensor([0.0, 0.3, 0.5], dtype=torch.float64)
+    with torch.no_grad():
+        ref = torchdiffeq_ref.odeint(rm.ode_func(ws, bs), z0, t, method=method)
+        fd = f.to(cuda)
+        out = ode_rl_amd.odeint(fd, z0.to(cuda), t, method=method).cpu()
+        base = ode_rl_amd.odeint(fd, clean.to(cuda), t, method=method).cpu()
+    assert bool(torch.isnan(ref[1:, 0]).any())
+    assert int((torch.isnan(ref) & ~torch.isnan(out)).sum()) == 0          # nothing the reference semantics keep NaN became a number
+    assert bool(torch.isfinite(out[:, 1]).all()) and torch.equal(out[:, 1], base[:, 1])
