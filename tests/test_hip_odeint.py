@@ -446,7 +446,9 @@ def test_persistent_dopri5_attempts_are_bit_identical(cuda, batch, rtol):
             out = ode_rl_amd.odeint(f, z0, t, rtol=rtol, atol=1e-5, method="dopri5")
             stats = dict(ode_rl_amd.last_stats)
         if batch > 16:
-            assert torch.equal(out, ref) and stats == ref_stats
+            # (`attempts_enqueued` is how far the HOST ran ahead of the device-side controller: timing, not arithmetic)
+            det = ("nfe", "n_accept", "n_reject", "accepted")
+            assert torch.equal(out, ref) and all(stats[k] == ref_stats[k] for k in det), (stats, ref_stats)
         else:
             # batches up to 16 take the sixteen-workgroup walk: every stored value of a layer is still bit-identical, but the error
             # norm is the sum of 64 partials per sample instead of 16 -- the ratio, hence the next step size, moves in its last bits
