@@ -28,6 +28,8 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "conv_common.h"
 #include "pack_elems.h"
 
@@ -375,6 +377,8 @@ int launch_wino5(const ConvArgs& a, hipStream_t stream) {
   for (int k = 8; k >= 2; k >>= 1)
     if (k <= split_max && nwg1 * k <= kSplit5Wgs && nchunk % k == 0 && nchunk / k >= 2 && !(a.debug & (256 | 512 | 1024 | 2048))) { S = k; break; }
   if (S > 1) {
+    static std::mutex split_mu;   // the scratch, its epoch and its (re)allocation: one caller at a time (autograd runs backward passes
+    std::lock_guard<std::mutex> lk(split_mu);   // on its own thread); launches that share it are ordered by the stream they go to
     Split5State& G = g_split5;
     const size_t need = (size_t)nwg1 * S * 4 * 4 * 64 * 4;
     if (!G.words) {
