@@ -355,6 +355,9 @@ static struct Split5State {
   size_t part_floats = 0;
   unsigned* words = nullptr;   // [count: kTiles x 4 | xcc: kWgs]
   unsigned epoch = 0;
+  int device = -1;             // the device the scratch lives on (one process drives one GPU: a call from another device is refused)
+  hipStream_t last_stream = nullptr;   // the stream of the previous split launch (compared, never dereferenced)
+  bool used = false;
 } g_split5;
 constexpr int kSplit5Tiles = 256, kSplit5Wgs = 256;
 
@@ -376,17 +379,29 @@ int launch_wino5(const ConvArgs& a, hipStream_t stream) {
   int S = 1;
   for (int k = 8; k >= 2; k >>= 1)
     if (k <= split_max && nwg1 * k <= kSplit5Wgs && nchunk % k == 0 && nchunk / k >= 2 && !(a.debug & (256 | 512 | 1024 | 2048))) { S = k; break; }
+  if (S > 1) {   // a captured launch would replay with this launch's epoch and scratch: graphs get the unsplit kernel (no shared state)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) S = 1;
+  }
   if (S > 1) {
     static std::mutex split_mu;   // the scratch, its epoch and its (re)allocation: one caller at a time (autograd runs backward passes
     std::lock_guard<std::mutex> lk(split_mu);   // on its own thread); launches that share it are ordered by the stream they go to
     Split5State& G = g_split5;
     const size_t need = (size_t)nwg1 * S * 4 * 4 * 64 * 4;
+    int cur_dev = -1;
+    ODEHIP_CHECK_HIP(hipGetDevice(&cur_dev));
     if (!G.words) {
       ODEHIP_CHECK_HIP(hipMalloc((void**)&G.words, (kSplit5Tiles * 4 + kSplit5Wgs) * sizeof(unsigned)));
       ODEHIP_CHECK_HIP(hipMemset(G.words, 0, (kSplit5Tiles * 4 + kSplit5Wgs) * sizeof(unsigned)));
+      G.device = cur_dev;
     }
+    ODEHIP_REQUIRE(cur_dev == G.device, "conv5x5: the split launches' scratch belongs to device %d, this call runs on device %d (one process drives one GPU)",
+                   G.device, cur_dev);
+    // the counters and partials are shared by consecutive launches: launches on ONE stream are ordered by it; a caller that changes
+    // streams waits for the device first (rare: the whole library is driven from one stream)
+    if (G.used && G.last_stream != stream) ODEHIP_CHECK_HIP(hipDeviceSynchronize());
     if (G.part_floats < need) {   // (rare, synchronous: a launch in flight may still use the old buffer)
-      ODEHIP_CHECK_HIP(hipStreamSynchronize(stream));
+      ODEHIP_CHECK_HIP(hipDeviceSynchronize());
       if (G.part) (void)hipFree(G.part);
       G.part = nullptr;
       G.part_floats = 0;
@@ -399,6 +414,8 @@ int launch_wino5(const ConvArgs& a, hipStream_t stream) {
     const dim3 grid((a.qout / 8) * 2 * S, a.batch);
     hipLaunchKernelGGL((conv5x5_wino_kernel<false, true>), grid, dim3(512), k5Lds, stream, a, sp5);
     ODEHIP_CHECK_HIP(hipGetLastError());
+    G.last_stream = stream;
+    G.used = true;
     return ODEHIP_OK;
   }
   const dim3 grid((a.qout / 8) * 2, a.batch);

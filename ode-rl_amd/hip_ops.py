@@ -1132,6 +1132,8 @@ def upsample2x(x):
 def upsample2x_backward(g):
     require_device_tensor(g, "gradient")
     g = g.contiguous()
+    if g.dim() < 2 or g.shape[-2] % 2 or g.shape[-1] % 2:
+        raise ValueError(f"upsample2x backward: needs (..., 2H, 2W), got {tuple(g.shape)}")
     h2, w2 = g.shape[-2:]
     gin = torch.empty(tuple(g.shape[:-2]) + (h2 // 2, w2 // 2), dtype=torch.float32, device=g.device)
     _lib.check(_lib.load().odehip_upsample2x_bilinear_backward(_ptr(g), _ptr(gin), gin.numel() // ((h2 // 2) * (w2 // 2)), h2 // 2, w2 // 2, _stream()))
@@ -1147,6 +1149,14 @@ def bn_relu_up_forward(x, bn, upsample):
     x = x.contiguous()
     n, c, h, w = x.shape
     dev = x.device
+    if bn.num_features != c or type(bn.momentum) is not float:   # (momentum=None -- a cumulative average -- is not built)
+        raise ValueError(f"bn_relu_up: BatchNorm2d({bn.num_features}, momentum={bn.momentum}) on a {c}-channel input")
+    for name in ("weight", "bias", "running_mean", "running_var"):
+        p = getattr(bn, name)
+        if p is not None:
+            require_device_tensor(p, f"BatchNorm2d.{name}")
+            if p.device != dev or p.numel() != c or not p.is_contiguous():
+                raise ValueError(f"bn_relu_up: BatchNorm2d.{name} must be a contiguous ({c},) tensor on {dev}")
     training = bn.training or bn.running_mean is None
     stats = torch.empty((4, c), dtype=torch.float32, device=dev)
     out = torch.empty((n, c, 2 * h, 2 * w) if upsample else (n, c, h, w), dtype=torch.float32, device=dev)
@@ -1168,6 +1178,8 @@ def bn_relu_up_backward(grad_out, x, saved, upsample):
     require_device_tensor(grad_out, "gradient")
     grad_out, x = grad_out.contiguous(), x.contiguous()
     n, c, h, w = x.shape
+    if tuple(grad_out.shape) != ((n, c, 2 * h, 2 * w) if upsample else (n, c, h, w)):
+        raise ValueError(f"bn_relu_up backward: gradient of shape {tuple(grad_out.shape)} for an input of shape {tuple(x.shape)} (upsample={bool(upsample)})")
     dev = x.device
     lib = _lib.load()
     gx = torch.empty_like(x)

@@ -17,7 +17,8 @@ def train_batch(model, batch_dict, optimizer, async_solver=False):
     error (dt underflow, non-finite state) then surfaces at loss.backward(), not inside the forward as in torchdiffeq.  A solve that
     needs more attempted steps than were enqueued up front is SEALED on the device (its unreached frames are NaN, never stale memory)
     and reported as AsyncSolveTruncated by the backward pass: nothing has touched the parameters at that point, so the step is
-    repeated here on the synchronous path (and the next asynchronous solve enqueues more attempts)."""
+    repeated here on the synchronous path, from the module buffers (BatchNorm statistics) of before the sealed pass (and the next
+    asynchronous solve enqueues more attempts)."""
     dev = next(model.parameters()).device
     inp = batch_dict["observed_data"].to(dev) + 0.5          # train_test.py:180: [-0.5, 0.5] -> [0, 1]
     out = batch_dict["data_to_predict"].to(dev) + 0.5
@@ -31,6 +32,9 @@ def train_batch(model, batch_dict, optimizer, async_solver=False):
         return pred, loss
 
     if async_solver:
+        # what a sealed pass could leave behind besides gradients (zeroed by the repeat): module buffers -- a BatchNorm behind the
+        # solver (VidODE's flow decoder) would fold the NaN frames into its running statistics
+        buffers = [(b, b.detach().clone()) for b in model.buffers()]
         was = hip_ops.set_async_dopri5(True)
         try:
             try:
@@ -39,6 +43,9 @@ def train_batch(model, batch_dict, optimizer, async_solver=False):
             finally:
                 hip_ops.set_async_dopri5(was)
         except _lib.AsyncSolveTruncated:
+            with torch.no_grad():
+                for b, kept in buffers:
+                    b.copy_(kept)
             pred, loss = step()
     else:
         pred, loss = step()

@@ -131,3 +131,50 @@ def test_train_batch_on_generated_frames(cuda):
         _, _, loss, _ = train_batch(model, bd, optim)
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_train_batch_repeats_a_sealed_asynchronous_step_from_clean_buffers():
+    """train_batch(async_solver=True): a forward whose dopri5 solve was sealed (AsyncSolveTruncated at the backward pass) has fed NaN frames
+    to everything behind the solver -- a BatchNorm there folds them into its running statistics.  The repeat must start from the
+    buffers of before the sealed pass and take exactly one optimiser step.  (Host logic only: a stub model on the CPU.)"""
+    from ode_rl_amd import _lib, hip_ops
+    from ode_rl_amd.train import train_batch
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+            self.bn = torch.nn.BatchNorm1d(3)
+            self.calls, self.async_seen = 0, []
+
+        def get_prediction(self, inp, batch_dict=None):
+            self.calls += 1
+            self.async_seen.append(hip_ops._async_dopri5)
+            x = inp * self.w
+            if self.calls == 1:   # the sealed pass: NaN frames reach the BatchNorm, the backward pass reports the truncation
+                self.bn(x * float("nan"))
+
+                class Sealed(torch.autograd.Function):
+                    @staticmethod
+                    def forward(ctx, v):
+                        return v.clone()
+
+                    @staticmethod
+                    def backward(ctx, g):
+                        raise _lib.AsyncSolveTruncated("sealed")
+                return Sealed.apply(x)
+            return self.bn(x)
+
+        def get_loss(self, pred, truth):
+            return ((pred - truth) ** 2).mean()
+
+    m = Stub()
+    optim = torch.optim.SGD(m.parameters(), lr=0.1)
+    bd = {"observed_data": torch.randn(8, 3), "data_to_predict": torch.randn(8, 3)}
+    was = hip_ops._async_dopri5
+    _, _, loss, _ = train_batch(m, bd, optim, async_solver=True)
+    assert m.calls == 2 and m.async_seen == [True, was]          # the repeat runs on the caller's (synchronous) setting
+    assert hip_ops._async_dopri5 == was
+    assert torch.isfinite(loss) and torch.isfinite(m.bn.running_mean).all() and torch.isfinite(m.bn.running_var).all()
+    assert int(m.bn.num_batches_tracked) == 1                    # one step's worth of statistics, not two
+    assert torch.isfinite(m.w).all() and not torch.equal(m.w.detach(), torch.ones(3))
