@@ -110,8 +110,9 @@ def test_a_lost_partner_in_a_trajectory_walk_is_loud(cuda):
 def test_a_lost_partner_in_a_single_evaluation_walk_is_loud(cuda):
     """The same fault in the encoder loop at batch 2, whose Euler steps run as single-evaluation walks since round 4 (batches up to 16;
     VERDICT r03: "no NaN guard -- keep it off"): there is no guard launch behind those, so the walk itself NaN-fills its outputs when a
-    wait of the launch gave up (nan_fill_row16).  The encoder's hidden states carry NaN (the lost workgroup's partners wrote them;
-    forward()'s (mean, std) sit behind the head's ReLUs, which map NaN to 0 here), the next call raises, the library is usable afterwards."""
+    wait of the launch gave up (nan_fill_row16).  The encoder's hidden states carry NaN (the lost workgroup's partners wrote them; they
+    are what is checked: when this test was written forward()'s (mean, std) sat behind ReLUs that mapped NaN to 0 -- the finding
+    behind test_a_non_finite_state_is_not_laundered), the next call raises, the library is usable afterwards."""
     import os
     if os.environ.get("ODEHIP_PERSISTENT") == "0" or os.environ.get("ODEHIP_PERSIST16") == "0" or os.environ.get("ODEHIP_EVAL_WALK") == "0":
         pytest.skip("single-evaluation walks are switched off for this run")
