@@ -32,8 +32,10 @@ SED[split5_drop_partial]='s/      for (int e = 0; e < 4; ++e) tot\[e\] = k == 0 
 SED[seal_no_nan]='s/  for (long long i = (long long)blockIdx.x \* 256 + threadIdx.x; i < n; i += (long long)gridDim.x \* 256) o\[i\] = nan;/  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) o[i] = 0.0f;/'   # sealed async solve: unreached frames zero instead of NaN
 SED[bn_bwd_mean_term]='s/  m2\[c\] = (float)(b \/ count);/  m2[c] = (float)(a \/ count);/'   # fused BatchNorm backward: the xhat term gets the wrong mean
 SED[bn_running_var_biased]='s/    const double unbiased = count > 1.0 ? var \* count \/ (count - 1.0) : var;/    const double unbiased = var;/'   # running_var updated with the biased variance
+SED[relu_launders_nan]='s/__device__ __forceinline__ float relu_f(float v) { return v < 0.0f ? 0.0f : v; }/__device__ __forceinline__ float relu_f(float v) { return fmaxf(v, 0.0f); }/'   # the ReLU of every epilogue back to v_max_f32: NaN -> 0
+SED[evalwalk_no_nan_fill]='s/      nan_fill_row16(\*(const ConvArgs\*)((ConstArgs\*)table + l), b, cq, rq, pa.reloc, pa.out_nchw);/      (void)0;/'   # sixteen-workgroup walk: a launch whose wait gave up leaves its outputs as they are
 SED[dopri5_beta32]='s|{44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0}|{44.0 / 45, -56.0 / 15, 31.0 / 9, 0, 0, 0}|'
-TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd tests/test_hip_vidode.py::test_upsample2x_matches_torch tests/test_hip_vidode.py::test_bn_relu_up_matches_torch tests/test_hip_backward.py::test_async_dopri5_forward_matches_the_synchronous_one"
+TESTS="tests/test_hip_backward.py::test_backward_strict_on_kink_free_dynamics tests/test_hip_frame_codec.py::test_encoder_matches_reference_fixture tests/test_hip_frame_codec.py::test_decoder_matches_reference_fixture tests/test_hip_conv.py::test_winograd5_conv_matches_torch tests/test_hip_full_size.py::test_cell_and_encoder_full_channels tests/test_hip_odeint.py::test_fixed_grid_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_dopri5_on_vigorous_dynamics_matches_reference_fixture tests/test_hip_odeint.py::test_fixed_grid_matches_golden_and_oracle tests/test_hip_odeint.py::test_full_size_against_oracle tests/test_hip_backward.py::test_dopri5_backward_matches_autograd_through_oracle tests/test_hip_backward.py::test_dopri5_adjoint_matches_oracle_adjoint tests/test_hip_backward.py::test_dopri5_saving_forward_equals_reintegration tests/test_hip_reference_configs.py::test_config0_as_stated_b4 tests/test_hip_encoder_backward.py::test_convgru_cell_backward_matches_autograd_through_oracle tests/test_hip_frame_codec.py::test_backward_matches_fp64_autograd tests/test_hip_vidode.py::test_upsample2x_matches_torch tests/test_hip_vidode.py::test_bn_relu_up_matches_torch tests/test_hip_backward.py::test_async_dopri5_forward_matches_the_synchronous_one tests/test_hip_errors.py::test_a_non_finite_state_is_not_laundered tests/test_hip_errors.py::test_a_lost_partner_in_a_single_evaluation_walk_is_loud"
 case "${1:-}" in
 build)
   for m in "${!SED[@]}"; do
