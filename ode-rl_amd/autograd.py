@@ -195,10 +195,10 @@ class _BnReluUpFn(torch.autograd.Function):
     """BatchNorm2d -> ReLU (-> bilinear x2 upsampling) in one pass (csrc/bn_relu_up.hip): VidODE's flow decoder, models/VidODE.py:34-36."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn, upsample):
-        out, saved = hip_ops.bn_relu_up_forward(x.detach(), bn, upsample)
+    def forward(ctx, x, weight, bias, conv_bias, bn, upsample):
+        out, saved = hip_ops.bn_relu_up_forward(x.detach(), bn, upsample, conv_bias=conv_bias)
         ctx.saved_stats, ctx.upsample = saved, upsample
-        ctx.affine = weight is not None
+        ctx.affine, ctx.has_conv_bias = weight is not None, conv_bias is not None
         ctx.save_for_backward(x.detach())
         return out
 
@@ -207,15 +207,22 @@ class _BnReluUpFn(torch.autograd.Function):
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         gx, gw, gb = hip_ops.bn_relu_up_backward(g, x, ctx.saved_stats, ctx.upsample)
-        return gx, (gw if ctx.affine else None), (gb if ctx.affine else None), None, None
+        gcb = None
+        if ctx.has_conv_bias:
+            # a constant in front of batch statistics has no gradient; in eval() mode d/db = sum of dx = scale * sum g_pre = scale * d beta
+            stats, training = ctx.saved_stats
+            gcb = torch.zeros_like(gb) if training else stats[2] * gb
+        return gx, (gw if ctx.affine else None), (gb if ctx.affine else None), gcb, None, None
 
 
-def bn_relu_up(x, bn, upsample):
+def bn_relu_up(x, bn, upsample, conv_bias=None):
     """relu(bn(x)), upsampled x2 if `upsample`; bn: nn.BatchNorm2d (train() or eval() as the module says; running statistics and
-    num_batches_tracked updated as the module itself would)."""
-    if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad)):
-        return _BnReluUpFn.apply(x, bn.weight, bn.bias, bn, bool(upsample))
-    return hip_ops.bn_relu_up_forward(x, bn, upsample)[0]
+    num_batches_tracked updated as the module itself would).  conv_bias: the bias of the convolution that produced x if the caller
+    left it out of the convolution (hip_ops.bn_relu_up_forward)."""
+    if torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad) or
+                                    (conv_bias is not None and conv_bias.requires_grad)):
+        return _BnReluUpFn.apply(x, bn.weight, bn.bias, conv_bias, bn, bool(upsample))
+    return hip_ops.bn_relu_up_forward(x, bn, upsample, conv_bias=conv_bias)[0]
 
 
 class _AdjointOdeint(torch.autograd.Function):

@@ -237,17 +237,105 @@ def test_bn_relu_up_matches_torch(cuda, shape, upsample, training):
 
 
 @pytest.mark.gpu
-def test_flow_decoder_fused_equals_module_by_module(cuda):
-    """The Decoder's fused forward (convolution -> one HIP pass for BatchNorm + ReLU + the next upsampling) against the same modules
-    called one by one (ODEHIP_FLOW_FUSED=0: MIOpen's BatchNorm, torch's ReLU, csrc/upsample.hip): output, every parameter gradient and
-    the BatchNorm buffers <= 1e-5, in train() and eval() mode."""
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("upsample", [True, False])
+def test_bn_relu_up_folds_the_convolution_bias(cuda, upsample, training):
+    """The fused pass with conv_bias= (the convolution in front ran WITHOUT its bias; VidODE.py's Encoder / Decoder do that): the same
+    as relu(bn(x + b)) in fp64 -- output <= 2e-6, gradients of x / gamma / beta <= 2e-5, running statistics <= 1e-6 (running_mean sees
+    the bias); the bias gradient is exactly zero under batch statistics (the reference gets round-off there) and sum(dx) in eval()."""
+    import copy
+    import torch.nn.functional as F
+    from ode_rl_amd.autograd import bn_relu_up
+    n, c, h, w = 4, 32, 16, 16
+    g = torch.Generator().manual_seed(11 + (2 if upsample else 0) + (1 if training else 0))
+    x = torch.randn(n, c, h, w, generator=g) * 1.5
+    cb = torch.randn(c, generator=g) * 0.7
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(c, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    bn.train(training)
+
+    def reference(xx):
+        ref_bn = copy.deepcopy(bn).double()
+        xr, br = xx.double().requires_grad_(True), cb.double().requires_grad_(True)
+        return ref_bn, xr, br, ref_bn(xr + br.view(1, -1, 1, 1))
+
+    ref_bn, xr, br, pre = reference(x)
+    with torch.no_grad():
+        near = pre.abs() < 1e-4
+    if bool(near.any()):   # off the ReLU kink, as in test_bn_relu_up_matches_torch
+        x = x + near.float() * 0.01
+        ref_bn, xr, br, pre = reference(x)
+    ref = torch.relu(pre)
+    if upsample:
+        ref = F.interpolate(ref, scale_factor=2, mode="bilinear", align_corners=False)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout.double())
+    bnd = copy.deepcopy(bn).to(cuda)
+    xd, cbd = x.to(cuda).requires_grad_(True), cb.to(cuda).requires_grad_(True)
+    out = bn_relu_up(xd, bnd, upsample, conv_bias=cbd)
+    tag = f"{upsample}.{training}"
+    assert out.shape == ref.shape and record(f"bn_relu_up.conv_bias.fwd.{tag}", rel_l2(out, ref)) <= 2e-6
+    out.backward(gout.to(cuda))
+    assert record(f"bn_relu_up.conv_bias.gx.{tag}", rel_l2(xd.grad, xr.grad)) <= 2e-5
+    assert rel_l2(bnd.weight.grad, ref_bn.weight.grad) <= 2e-5 and rel_l2(bnd.bias.grad, ref_bn.bias.grad) <= 2e-5
+    assert record(f"bn_relu_up.conv_bias.running_mean.{tag}", rel_l2(bnd.running_mean, ref_bn.running_mean)) <= 1e-6
+    assert rel_l2(bnd.running_var, ref_bn.running_var) <= 1e-6
+    assert int(bnd.num_batches_tracked) == int(ref_bn.num_batches_tracked) == (1 if training else 0)
+    if training:
+        assert float(cbd.grad.abs().max()) == 0.0 and float(br.grad.abs().max()) <= 1e-9 * float(gout.abs().sum())
+    else:
+        assert record(f"bn_relu_up.conv_bias.gb.{tag}", rel_l2(cbd.grad, br.grad)) <= 2e-5
+    with torch.no_grad():   # without a graph: the same numbers, the same buffers
+        bnd3 = copy.deepcopy(bn).to(cuda)
+        assert torch.equal(bn_relu_up(x.to(cuda), bnd3, upsample, conv_bias=cb.to(cuda)), out.detach())
+        assert torch.equal(bnd3.running_mean, bnd.running_mean) and torch.equal(bnd3.running_var, bnd.running_var)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta", [12.0, 0.0])
+def test_flow_decoder_fused_equals_module_by_module(cuda, beta):
+    """The Decoder's fused forward (bias-free convolution -> one HIP pass for the bias, BatchNorm, ReLU and the next upsampling) against
+    the same modules called one by one (ODEHIP_FLOW_FUSED=0: MIOpen's BatchNorm, torch's ReLU, csrc/upsample.hip), in train() and eval()
+    mode: output and BatchNorm buffers <= 1e-5, input and parameter gradients <= 1e-4.
+    The two paths round the pre-activations differently (the fused pass folds the convolution's bias into BatchNorm's shift instead of
+    adding it to x first), so with the modules' own initialisation (beta = 0) a pre-activation within an ulp of 0 may take the other ReLU
+    branch in one of them -- and ONE such pixel among 2.4 M moves every gradient below it by ~1e-3 in rel-L2 (it is one of ~6,000
+    random-sign terms of a weight gradient's entries, and reaches 0.6 % of the input gradient through the convolutions; observed: 9.4e-4
+    in eval() mode on the initial (0, 1) running statistics, tools/experiments/dbg_bn_fold.py) without anything being wrong.  So the strict comparison runs with BatchNorm biases of +12 (every unit active: the
+    whole chain of bias folding, statistics, normalisation, upsampling and their backward is compared, no kink in reach), and the
+    beta = 0 case keeps the strict bounds on the forward and the buffers and 5e-3 on the gradients -- a wrong term shows up at O(1).
+    The ReLU mask itself is pinned off the kink, against fp64, by test_bn_relu_up_matches_torch / _folds_the_convolution_bias."""
     import copy
     import os
     from ode_rl_amd.models.VidODE import Decoder
     torch.manual_seed(3)
     dec = Decoder(256, 4, 2).to(cuda)
+    if beta:
+        with torch.no_grad():
+            for m in dec.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.bias.fill_(beta)
     x = torch.randn(6, 256, 16, 16, device=cuda)
     gout = torch.randn(6, 4, 64, 64, device=cuda)
+    # running statistics of THIS input (one train() pass with momentum 1, module by module): eval() mode then normalises as train() mode
+    # does -- with the initial (0, 1) statistics the second block's pre-activations have a spread of ~7 and beta = 12 would not keep
+    # them off the kink -- and the eval() comparison runs on non-trivial buffers
+    bns = [m for m in dec.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    os.environ["ODEHIP_FLOW_FUSED"] = "0"
+    try:
+        for m in bns:
+            m.momentum = 1.0
+        with torch.no_grad():
+            dec.train()(x)
+    finally:
+        os.environ.pop("ODEHIP_FLOW_FUSED")
+        for m in bns:
+            m.momentum = 0.1
+    gtol = 1e-4 if beta else 5e-3
     for training in (True, False):
         res = []
         for fused in ("1", "0"):
@@ -261,16 +349,16 @@ def test_flow_decoder_fused_equals_module_by_module(cuda):
                 os.environ.pop("ODEHIP_FLOW_FUSED")
             res.append((out.detach(), xi.grad, [p.grad for p in d.parameters()], [b.clone() for b in d.buffers()]))
         a, b = res
-        assert record(f"flow_decoder.fused.out.{training}", rel_l2(a[0], b[0])) <= 1e-5
-        assert record(f"flow_decoder.fused.gx.{training}", rel_l2(a[1], b[1])) <= 1e-4
+        assert record(f"flow_decoder.fused.out.beta{beta}.{training}", rel_l2(a[0], b[0])) <= 1e-5
+        assert record(f"flow_decoder.fused.gx.beta{beta}.{training}", rel_l2(a[1], b[1])) <= gtol
         names = [n for n, _ in dec.named_parameters()]
         for n, u, v in zip(names, a[2], b[2]):
             if training and n in ("cnn_decoder.1.bias", "cnn_decoder.5.bias"):
-                # the bias of a convolution in front of a batch-statistics BatchNorm has NO gradient (the mean is subtracted again):
-                # both paths produce round-off noise around 0, eight orders below the weight gradients
+                # the bias of a convolution in front of a batch-statistics BatchNorm has NO gradient (the mean is subtracted again): the
+                # fused path returns exact zeros, the modules round-off noise around 0, eight orders below the weight gradients
                 scale = float(a[2][names.index(n.replace("bias", "weight"))].abs().max())
-                assert float(u.abs().max()) <= 1e-4 * scale and float(v.abs().max()) <= 1e-4 * scale
+                assert float(u.abs().max()) == 0.0 and float(v.abs().max()) <= 1e-4 * scale
             else:
-                assert rel_l2(u, v) <= 1e-4, n
+                assert record(f"flow_decoder.fused.grad.{n}.beta{beta}.{training}", rel_l2(u, v)) <= gtol, n
         for u, v in zip(a[3], b[3]):
             assert rel_l2(u.float(), v.float()) <= 1e-5
