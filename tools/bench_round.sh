@@ -28,6 +28,8 @@ run config2_adjoint_mixed --method dopri5 --train --adjoint --adjoint-norm mixed
 run config2_adjoint_atol1e-6 --method dopri5 --train --adjoint --rtol 1e-5 --atol 1e-6 --no-cpu-baseline --steps 20 --no-model --no-config0
 run config3_vidode_fwd --shape V --no-cpu-baseline --no-config0 --no-model
 run config3_vidode_train --shape V --train --no-cpu-baseline --no-model
+run config3_vidode_dopri5_fwd --shape V --method dopri5 --no-cpu-baseline --no-config0 --no-model
+run config3_vidode_dopri5_train --shape V --method dopri5 --train --no-cpu-baseline --no-config0 --no-model
 run config4_bf16_fwd --dtype bf16 --batch 128 --frames 40 --no-cpu-baseline --no-config0 --steps 20 --no-model
 run config4_bf16_train --dtype bf16 --batch 128 --frames 40 --train --no-cpu-baseline --steps 10 --no-model
 run bf16_b64_t10_fwd --dtype bf16 --no-cpu-baseline --no-config0 --no-model
