@@ -125,6 +125,65 @@ def test_dopri5_controller_pieces():
     assert abs(mid - math.exp(-0.1)) < 5e-7  # 4th-order dense output, h = 0.2
 
 
+def test_initial_step_is_hairers_algorithm_as_scipy_implements_it():
+    """torchdiffeq's `_select_initial_step` is the starting-step heuristic of Hairer, Norsett & Wanner (II.4) with the RMS norm, called with
+    order = 4 for dopri5 -- the algorithm scipy's RK45 uses (`scipy.integrate._ivp.common.select_initial_step`, same constants: 0.01,
+    1e-5, 1e-6, 100 h0, exponent 1 / (order + 1)).  An independent implementation of the published algorithm: the restatement must
+    reproduce its value (scipy's two extra bounds -- interval length, max_step -- are kept out of reach)."""
+    from scipy.integrate._ivp.common import select_initial_step
+    rms = lambda x: x.pow(2).mean().sqrt()
+    cases = [
+        (lambda t, y: np.array([y[1], 1.5 * (1 - y[0] ** 2) * y[1] - y[0]]), [2.0, 0.3], 1e-6, 1e-9),       # van der Pol
+        (lambda t, y: np.array([-0.5 * y[0] + 2.0 * y[1], -2.0 * y[0] - 0.5 * y[1], np.sin(t) - y[2]]), [1.0, 0.5, -2.0], 1e-4, 1e-5),
+        (lambda t, y: np.array([1e-7 * y[0]]), [1e-9], 1e-3, 1e-3),                                          # d0 < 1e-5: h0 = 1e-6
+    ]
+    for fun, y0, rtol, atol in cases:
+        y0n = np.array(y0, dtype=np.float64)
+        want = select_initial_step(fun, 0.25, y0n, 1e9, np.inf, fun(0.25, y0n), 1.0, 4, rtol, atol)
+        ft = lambda t, y: torch.from_numpy(np.asarray(fun(float(t), y.numpy())))
+        t0, y0t = torch.tensor(0.25, dtype=torch.float64), torch.from_numpy(y0n)
+        got = td._select_initial_step(ft, t0, y0t, 4, rtol, atol, ft(t0, y0t), rms)
+        assert float(got) == pytest.approx(float(want), rel=1e-12)
+
+
+def test_error_ratio_is_the_scaled_rms_norm_scipy_uses():
+    """One dopri5 step: the restatement's error ratio = RMS(err / (atol + rtol max(|y0|, |y1|))) is 2/3 of scipy RK45's
+    `_estimate_error_norm` for the same step: same tableau (the step result agrees to round-off), same scale and norm, and torchdiffeq's
+    error weights are Shampine's, 2/3 of the Dormand-Prince ones scipy uses (test_tableau_matches_scipy_rk45)."""
+    from scipy.integrate import RK45
+    fun = lambda t, y: np.array([y[1], 1.5 * (1 - y[0] ** 2) * y[1] - y[0]])
+    y0n, h, rtol, atol = np.array([2.0, 0.3]), 0.05, 1e-6, 1e-9
+    solver = RK45(fun, 0.0, y0n, 10.0, rtol=rtol, atol=atol, first_step=h)
+    from scipy.integrate._ivp.rk import rk_step
+    y_new, f_new = rk_step(fun, 0.0, y0n, fun(0.0, y0n), h, solver.A, solver.B, solver.C, solver.K)
+    scale = atol + np.maximum(np.abs(y0n), np.abs(y_new)) * rtol
+    want = solver._estimate_error_norm(solver.K, h, scale)
+    ft = lambda t, y: torch.from_numpy(np.asarray(fun(float(t), y.numpy())))
+    y0t, t0, dt = torch.from_numpy(y0n), torch.tensor(0.0, dtype=torch.float64), torch.tensor(h, dtype=torch.float64)
+    y1, f1, err, k = td._rk_step(ft, y0t, ft(t0, y0t), t0, dt, t0 + dt)
+    np.testing.assert_allclose(y1.numpy(), y_new, rtol=1e-13, atol=0)
+    got = td._error_ratio(err, rtol, atol, y0t, y1, lambda x: x.pow(2).mean().sqrt())
+    assert float(got) == pytest.approx(2.0 / 3.0 * float(want), rel=1e-9)
+
+
+def test_order_conditions_on_polynomial_solutions():
+    """Known answers that pin every coefficient at once: on dy/dt = 4 t^3 (solution t^4) a 5(4) pair is exact in both solutions, so the
+    error estimate vanishes, and torchdiffeq's quartic dense output (the mid-point weights DP_C_MID + `_interp_fit`) reproduces the
+    solution at ANY point of the step; on dy/dt = 5 t^4 the 5th-order solution is still exact and the 4th-order one is not."""
+    t0, dt = torch.tensor(0.3, dtype=torch.float64), torch.tensor(0.5, dtype=torch.float64)
+    y0 = torch.tensor([0.7], dtype=torch.float64)
+    f4 = lambda t, y: (4 * t ** 3).reshape(1).to(torch.float64)
+    y1, f1, err, k = td._rk_step(f4, y0, f4(t0, y0), t0, dt, t0 + dt)
+    assert abs(float(y1) - (0.7 + 0.8 ** 4 - 0.3 ** 4)) < 1e-14 and abs(float(err)) < 1e-15
+    co = td._interp_fit(y0, y1, k, dt)
+    for x in (0.3, 0.35, 0.5, 0.61, 0.8):
+        got = float(td._interp_evaluate(co, t0, t0 + dt, torch.tensor(x, dtype=torch.float64)))
+        assert abs(got - (0.7 + x ** 4 - 0.3 ** 4)) < 1e-14, x
+    f5 = lambda t, y: (5 * t ** 4).reshape(1).to(torch.float64)
+    y1, f1, err, k = td._rk_step(f5, y0, f5(t0, y0), t0, dt, t0 + dt)
+    assert abs(float(y1) - (0.7 + 0.8 ** 5 - 0.3 ** 5)) < 1e-14 and abs(float(err)) > 1e-6
+
+
 def test_reversed_time_negates_dynamics():
     A = torch.tensor([[-0.5, 1.0], [-1.0, -0.5]], dtype=torch.float64)
     y0 = torch.tensor([[1.0, 0.0]], dtype=torch.float64)
