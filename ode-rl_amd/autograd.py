@@ -309,13 +309,19 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     torchdiffeq's default mixed norm (every parameter tensor's error ratio steers the steps too) or, with
     `adjoint_options={"norm": "seminorm"}`, with the cheaper seminorm; `max_accept` in adjoint_options bounds the accepted
     backward steps whose activations are kept."""
-    from .odeint import FIXED_GRID, _check_monotone, _host_times, conv_stack_of, odeint
+    from .odeint import FIXED_GRID, _check_monotone, _host_times, check_options, conv_stack_of, odeint
     if method is None:
         method = "dopri5"
     if method not in FIXED_GRID and method != "dopri5":
         raise ValueError('Invalid method "{}". Must be one of euler, midpoint, rk4, dopri5'.format(method))
     if adjoint_method is not None and adjoint_method != method:
         raise NotImplementedError("odeint_adjoint(HIP): adjoint_method must equal method")
+    check_options(method, options, "odeint_adjoint")
+    if adjoint_params is not None and ({id(p) for p in adjoint_params} != {id(p) for p in func.parameters()}):
+        # torchdiffeq integrates a_theta for exactly these tensors; this path always does so for every parameter of `func`
+        raise NotImplementedError("odeint_adjoint(HIP): adjoint_params must be omitted or be all of func.parameters()")
+    if method in FIXED_GRID and adjoint_options:
+        raise ValueError(f"odeint_adjoint(HIP): unsupported {method} adjoint_options {sorted(adjoint_options)}")
     if not torch.is_grad_enabled() or not (y0.requires_grad or any(p.requires_grad for p in func.parameters())):
         return odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
     hip_ops.require_device_tensor(y0, "y0")
@@ -337,9 +343,6 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     if unknown:
         raise ValueError(f"odeint_adjoint(HIP): unsupported adjoint_options {sorted(unknown)}")
     options = options or {}
-    unknown = set(options) - {"first_step", "max_num_steps"}
-    if unknown:
-        raise ValueError(f"odeint_adjoint(HIP): unsupported dopri5 options {sorted(unknown)}")
     cfg = dict(rtol=float(rtol), atol=float(atol), first_step=float(options.get("first_step") or 0.0),
                max_num_steps=int(options.get("max_num_steps") or 0),
                adjoint_rtol=float(rtol if adjoint_rtol is None else adjoint_rtol),
@@ -349,7 +352,8 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
 
 
 def odeint_with_grad(func, y0, t, rtol, atol, method, options=None):
-    from .odeint import FIXED_GRID, _check_monotone, _host_times, conv_stack_of
+    from .odeint import FIXED_GRID, _check_monotone, _host_times, check_options, conv_stack_of
+    check_options(method, options)
     th = _host_times(t)
     _check_monotone(th)
     if len(th) > 1 and bool(th[0] > th[1]):
@@ -361,9 +365,6 @@ def odeint_with_grad(func, y0, t, rtol, atol, method, options=None):
     if method in FIXED_GRID:
         return _FixedGridOdeint.apply(y0, th, method, stack, *params)
     options = options or {}
-    unknown = set(options) - {"first_step", "max_num_steps"}
-    if unknown:
-        raise ValueError(f"odeint(HIP): unsupported dopri5 options {sorted(unknown)}")
     cfg = dict(rtol=float(rtol), atol=float(atol), first_step=float(options.get("first_step") or 0.0),
                max_num_steps=int(options.get("max_num_steps") or 0))
     return _Dopri5Odeint.apply(y0, th, cfg, stack, *params)

@@ -62,11 +62,22 @@ def conv_stack_of(func):
     return stack
 
 
+def check_options(method, options, where="odeint"):
+    """torchdiffeq's `options` that this path implements: none for the fixed-grid methods (one step per output interval; `step_size`,
+    `grid_constructor`, `perturb` and `interp` would change the result and are refused rather than ignored), `first_step` and
+    `max_num_steps` for dopri5."""
+    known = set() if method in FIXED_GRID else {"first_step", "max_num_steps"}
+    unknown = set(options or {}) - known
+    if unknown:
+        raise ValueError(f"{where}(HIP): unsupported {method} options {sorted(unknown)}")
+
+
 def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     if method is None:
         method = "dopri5"
     if method not in ("euler", "midpoint", "rk4", "dopri5"):
         raise ValueError('Invalid method "{}". Must be one of euler, midpoint, rk4, dopri5'.format(method))
+    check_options(method, options)
     hip_ops.require_device_tensor(y0, "y0")
     if torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in func.parameters())):
         from .autograd import odeint_with_grad
@@ -83,11 +94,10 @@ def odeint_forward(func, y0, t, rtol, atol, method, options=None):
         negate = True
     stack = conv_stack_of(func)
     if method in FIXED_GRID:
+        check_options(method, options)
         return hip_ops.odeint_fixed(stack, method, y0, th, negate=negate)
+    check_options(method, options)
     options = options or {}
-    unknown = set(options) - {"first_step", "max_num_steps"}
-    if unknown:
-        raise ValueError(f"odeint(HIP): unsupported dopri5 options {sorted(unknown)}")
     if hip_ops._async_dopri5 and not negate:   # enqueue only; the stats are read when somebody looks at them
         out, pending = hip_ops.odeint_dopri5_start(stack, y0, th, rtol, atol, first_step=float(options.get("first_step") or 0.0),
                                                    max_steps=int(options.get("max_num_steps") or 0))

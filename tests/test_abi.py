@@ -62,6 +62,34 @@ def test_no_cpu_fallback():
         ode_rl_amd.odeint(f, torch.zeros(1, 64, 16, 16), torch.tensor([0.0, 1.0]), method="rk4")
 
 
+def test_options_the_path_does_not_implement_are_refused_not_ignored():
+    """torchdiffeq's fixed-grid solvers take options (step_size, grid_constructor, perturb, interp) that change the result, its
+    dopri5 takes more than first_step / max_num_steps, and odeint_adjoint's adjoint_params selects the tensors a_theta is integrated
+    for: each is either implemented or raises -- checked before any tensor is looked at, so on the CPU too."""
+    import ode_rl_amd
+    f = ode_rl_amd.ODEFunc(64, 64, 3, 64, False, "relu", final_act=False)
+    z, t = torch.zeros(1, 64, 16, 16), torch.tensor([0.0, 1.0])
+    with pytest.raises(ValueError, match="step_size"):
+        ode_rl_amd.odeint(f, z, t, method="rk4", options={"step_size": 0.05})
+    with pytest.raises(ValueError, match="perturb"):
+        ode_rl_amd.odeint(f, z, t, method="euler", options={"perturb": True})
+    with pytest.raises(ValueError, match="dtype"):
+        ode_rl_amd.odeint(f, z, t, method="dopri5", options={"first_step": 0.1, "dtype": torch.float32})
+    with pytest.raises(ValueError, match="Invalid method"):
+        ode_rl_amd.odeint(f, z, t, method="adams")
+    with pytest.raises(ValueError, match="step_size"):
+        ode_rl_amd.odeint_adjoint(f, z, t, method="rk4", options={"step_size": 0.05})
+    with pytest.raises(ValueError, match="norm"):
+        ode_rl_amd.odeint_adjoint(f, z, t, method="rk4", adjoint_options={"norm": "seminorm"})
+    with pytest.raises(NotImplementedError, match="adjoint_params"):
+        ode_rl_amd.odeint_adjoint(f, z, t, method="dopri5", adjoint_params=tuple(list(f.parameters())[:2]))
+    with pytest.raises(NotImplementedError, match="adjoint_method"):
+        ode_rl_amd.odeint_adjoint(f, z, t, method="dopri5", adjoint_method="rk4")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # every option accepted: the next thing looked at is the tensor
+        ode_rl_amd.odeint_adjoint(f, z, t, method="dopri5", options={"first_step": 0.1}, adjoint_params=tuple(f.parameters()),
+                                  adjoint_options={"norm": "seminorm"})
+
+
 def test_state_dict_layout_matches_reference_fixture():
     """Drop-in: same parameter names/shapes as the reference's ODEFunc (keys captured in the fixture)."""
     import numpy as np
