@@ -178,3 +178,97 @@ def test_train_batch_repeats_a_sealed_asynchronous_step_from_clean_buffers():
     assert torch.isfinite(loss) and torch.isfinite(m.bn.running_mean).all() and torch.isfinite(m.bn.running_var).all()
     assert int(m.bn.num_batches_tracked) == 1                    # one step's worth of statistics, not two
     assert torch.isfinite(m.w).all() and not torch.equal(m.w.detach(), torch.ones(3))
+
+
+def test_async_dopri5_attempt_budget_follows_the_previous_solve(monkeypatch):
+    """The policy of ode_rl_amd.hip_ops.PendingDopri5.collect (host logic, the library call stubbed): the next asynchronous solve
+    enqueues what the last one used plus a quarter (at least 2 more, at least 4, at most ASYNC_ATTEMPTS_MAX), keeps its budget while
+    the need stays within [half, all] of it, doubles on a sealed solve (AsyncSolveTruncated), and a failed solve raises the same error
+    at every later look."""
+    from ode_rl_amd import _lib, hip_ops
+    real = _lib.load()
+    script = []   # (rc, n_accept, n_reject, enqueued) per collect call
+
+    class Stub:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def odehip_odeint_dopri5_collect(self, token, stats, log, cap, saved):
+            rc, acc, rej, enq = script.pop(0)
+            stats[0], stats[1], stats[2], stats[3] = 2 + 6 * (acc + rej), acc, rej, enq
+            return rc
+
+        def odehip_last_error(self):
+            return b"stub: sealed"
+
+    monkeypatch.setattr(_lib, "load", lambda: Stub())
+    monkeypatch.setattr(hip_ops, "_async_attempts", 8)
+    monkeypatch.setattr(hip_ops, "_pending_solves", [])
+
+    def collect(rc, acc, rej):
+        script.append((rc, acc, rej, hip_ops._async_attempts))
+        p = hip_ops.PendingDopri5(0, None, 0, None)
+        return p, p.collect
+
+    p, c = collect(0, 2, 0)            # used 2 of 8: want 4, exactly half of the budget -> the budget stays
+    st, saved = c()
+    assert st["n_accept"] == 2 and saved is None and hip_ops._async_attempts == 8 and not hip_ops._pending_solves
+    assert c() is p._result            # a second look does not call the library again (the script is empty)
+    collect(0, 1, 0)[1]()              # used 1: want 3, less than half of 8 -> follow it down, never below 4
+    assert hip_ops._async_attempts == 4
+    collect(0, 3, 0)[1]()              # used 3 of 4: within [half, all] -> want 5 > 4 -> 5
+    assert hip_ops._async_attempts == 5
+    collect(0, 3, 1)[1]()              # used 4: want 6
+    assert hip_ops._async_attempts == 6
+    collect(0, 3, 0)[1]()              # used 3: want 5, not above 6 and 2 * 5 >= 6 -> keep 6
+    assert hip_ops._async_attempts == 6
+    collect(0, 30, 10)[1]()            # used 40: want 50
+    assert hip_ops._async_attempts == 50
+    p, c = collect(-5, 40, 10)         # sealed at 50 attempts: the next solve gets 100, and the error sticks to this one
+    with pytest.raises(_lib.AsyncSolveTruncated):
+        c()
+    assert hip_ops._async_attempts == 100 and not hip_ops._pending_solves
+    with pytest.raises(_lib.AsyncSolveTruncated):
+        c()
+    hip_ops._async_attempts = 200
+    with pytest.raises(_lib.AsyncSolveTruncated):
+        collect(-5, 150, 50)[1]()
+    assert hip_ops._async_attempts == hip_ops.ASYNC_ATTEMPTS_MAX == 256
+    collect(0, 1000, 0)[1]()           # capped
+    assert hip_ops._async_attempts == 256
+
+
+def test_last_stats_fills_itself_on_first_access():
+    """ode_rl_amd.last_stats after an asynchronous solve (hip_ops.LazyStats): bound to the pending solve, it collects on the FIRST look
+    of any kind -- and a failed solve raises there -- then behaves as the plain dict the synchronous path fills."""
+    from ode_rl_amd import hip_ops
+
+    class Pending:
+        def __init__(self, result):
+            self.result, self.collected = result, 0
+
+        def collect(self):
+            self.collected += 1
+            if isinstance(self.result, BaseException):
+                raise self.result
+            return self.result, None
+
+    for look in (lambda d: d["nfe"], lambda d: d.get("nfe"), lambda d: "nfe" in d, lambda d: len(d), lambda d: list(d), lambda d: d.keys(),
+                 lambda d: d.items(), lambda d: d.values(), lambda d: d.copy(), lambda d: repr(d), lambda d: d == {}):
+        d, p = hip_ops.LazyStats(), Pending({"nfe": 14, "n_accept": 2})
+        d["stale"] = 1
+        d._bind(p)
+        assert p.collected == 0
+        look(d)
+        assert p.collected == 1 and dict.__getitem__(d, "nfe") == 14 and "stale" not in d
+        look(d)
+        assert p.collected == 1
+    d, p = hip_ops.LazyStats(), Pending(AssertionError("underflow in dt"))
+    d._bind(p)
+    with pytest.raises(AssertionError, match="underflow"):
+        d["nfe"]
+    assert len(d) == 0 and p.collected == 1     # the error was reported once; the dict is empty afterwards
+    d._bind(Pending({"nfe": 8}))
+    d.clear()                                    # the synchronous path clears before it fills: a pending solve is dropped, not collected
+    d.update({"nfe": 20})
+    assert d["nfe"] == 20
